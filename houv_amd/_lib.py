@@ -1,0 +1,92 @@
+"""ctypes binding of libhouv_hip.so (include/houv_hip.h).
+
+There is NO fallback: if the HIP library is missing or a call fails, this raises.  The oracle under
+``oracle/`` is never imported from here.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libhouv_hip.so")
+ABI_VERSION = 1
+
+_c_f = ctypes.c_void_p     # device pointers travel as plain addresses
+_int = ctypes.c_int
+_dbl = ctypes.c_double
+_flt = ctypes.c_float
+
+_SIGNATURES = {
+    "houv_abi_version": (ctypes.c_int, []),
+    "houv_last_error": (ctypes.c_char_p, []),
+    "houv_chamfer_forward": (ctypes.c_int, [_c_f, _c_f, _int, _int, _int, _c_f, _c_f, _c_f, _c_f, _c_f]),
+    "houv_chamfer_backward": (ctypes.c_int, [_c_f, _c_f, _int, _int, _int, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f]),
+    "houv_kabsch": (ctypes.c_int, [_c_f, _c_f, _c_f, _int, _int, _c_f, _c_f, _c_f]),
+    "houv_solve_iterate": (ctypes.c_int, [_c_f, _c_f, _int, _int, _int, _int, _c_f, _int, _int, _int, _int, _int, _int,
+                                          _int, _int, _dbl, _dbl, _dbl, _dbl, _flt, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f,
+                                          _c_f]),
+    "houv_pose_forward": (ctypes.c_int, [_c_f, _int, _int, _int, _c_f, _int, _c_f, _c_f, _c_f, _c_f]),
+}
+
+_lib = None
+
+
+class HouvHipError(RuntimeError):
+    pass
+
+
+def exported_symbols():
+    return sorted(_SIGNATURES)
+
+
+def load():
+    """Load libhouv_hip.so once; raise (never fall back) when it is absent or ABI-mismatched."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HouvHipError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C houv_amd/csrc`). houv_amd has no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError here = symbol missing from the build
+        fn.restype = res
+        fn.argtypes = args
+    if lib.houv_abi_version() != ABI_VERSION:
+        raise HouvHipError(f"libhouv_hip.so ABI {lib.houv_abi_version()} != expected {ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+def last_error():
+    return load().houv_last_error().decode("utf-8", "replace")
+
+
+def check(ok, what):
+    if ok != 1:
+        raise HouvHipError(f"{what} failed: {last_error()}")
+
+
+def ptr(t):
+    """Device address of a tensor (None -> NULL)."""
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def stream_of(t):
+    """The torch current stream of t's device as a raw hipStream_t."""
+    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def require_gpu(*tensors, dtype=None):
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise HouvHipError("houv_amd ops run on an MI355X only: got a CPU tensor (there is no CPU fallback)")
+        if not t.is_contiguous():
+            raise HouvHipError("houv_amd ops need contiguous tensors")
+    dev = [t.device for t in tensors if t is not None]
+    if any(d != dev[0] for d in dev):
+        raise HouvHipError("all tensors must live on the same device")

@@ -1,0 +1,66 @@
+// houv_common.h -- shared device helpers + host error plumbing for libhouv_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "houv_math.h"
+
+namespace houv {
+
+constexpr int kWave = 64;     // CDNA wavefront
+constexpr int kSub = 32;      // reference points per arg-min tracking sub-tile (see DESIGN.md "deferred index")
+
+// ---- host side ---------------------------------------------------------------------------------
+void set_error(const char* fmt, ...);
+inline bool check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_error("%s: %s", what, hipGetErrorString(e));
+    return false;
+  }
+  return true;
+}
+
+// ---- device side -------------------------------------------------------------------------------
+// The four squared distances share dx,dy,dz.  MET 0: full 3-D; MET 1/2/3: coordinate x/y/z dropped
+// (loss_view, registration/model_utils_completion.py:157-166).  The expression trees are fixed
+// (explicit fma, compiled with -ffp-contract=off) so that the sweep and the index-recovery rescan
+// produce bit-identical values.  MET 0 equals fma(dz,dz,fma(dy,dy,dx*dx)), the contraction nvcc
+// applies to the reference's x2*x2+y2*y2+z2*z2 (chamfer3D.cu:33-36).
+template <int MET>
+__device__ __forceinline__ float metric_sqdist(float dx, float dy, float dz) {
+  if constexpr (MET == 0) return __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+  else if constexpr (MET == 1) return __builtin_fmaf(dz, dz, dy * dy);
+  else if constexpr (MET == 2) return __builtin_fmaf(dz, dz, dx * dx);
+  else return __builtin_fmaf(dy, dy, dx * dx);
+}
+
+__device__ __forceinline__ float min3f(float a, float b, float c) {
+  return __builtin_fminf(__builtin_fminf(a, b), c);   // -> v_min3_f32
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, kWave);
+  return v;
+}
+
+__device__ __forceinline__ int wave_sum_i(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, kWave);
+  return v;
+}
+
+// inclusive prefix sum across the 64 lanes of a wave
+__device__ __forceinline__ int wave_incl_scan_i(int v) {
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    int n = __shfl_up(v, o, kWave);
+    if (lane >= o) v += n;
+  }
+  return v;
+}
+
+}  // namespace houv

@@ -1,0 +1,538 @@
+// solve.hip -- the fused HOUV optimisation loop for gfx950 (MI355X).
+//
+// One workgroup owns one hypothesis (pair p, restart k) for the whole loop:
+//   pose from 8 scalars -> move the source cloud -> 4-metric bidirectional Chamfer (two LDS-resident
+//   brute-force sweeps) -> top-k robust loss -> closed-form gradient -> Adam step, `n_iters` times,
+// with both clouds resident in LDS and NOTHING but the 24-double state touching HBM in between.
+// It replaces the PyTorch loop of predict_model (registration/models/houv.py:106-138; loss :209-222,
+// model_utils_completion.py:83-100,157-166) and of getPredict_angle (registration/train_utils.py:359-456),
+// which per iteration launches 8 NmDistanceKernel + 8 NmDistanceGradKernel + 8 topk + ~150 small kernels
+// on K-fold replicated clouds.
+//
+// Design notes (DESIGN.md has the long form):
+//   * sweep: every lane owns Q query points in registers; reference points are read from LDS with
+//     wave-uniform ds_read_b128 (broadcast), two at a time; the four squared distances (full + three
+//     axis-dropped views) share dx,dy,dz: 3 sub + 2 mul + 4 fma + 4 min3/2 = 11 VALU ops per point pair;
+//   * arg-min is deferred: a per-32-reference sub-tile id is tracked (3 ops per 32 refs) and the exact
+//     NN is recovered by re-evaluating that sub-tile with bit-identical arithmetic;
+//   * no distance/index arrays are ever materialised: the epilogue of each sweep turns (NN, dist)
+//     straight into the 13 sums the parameter gradient needs (sum sqrt d, sum G, sum G p^T);
+//   * top-k (k = N/2 for the full metric) = exact 4-pass 8-bit radix select on the fp32 bit patterns
+//     of the register-resident distances, LDS histogram;
+//   * the un-moved source point needed for sum G p^T in the target->moved direction is R^T(p' - T).
+#include "../../include/houv_hip.h"
+#include "houv_common.h"
+
+namespace houv {
+namespace {
+
+struct SolveArgs {
+  const float* src;
+  const float* tgt;
+  int P, N, M, K;
+  double* state;
+  int steps_done, n_iters, angle_base, trans_mode, f64_params, k_full, k_view;
+  double lr, beta1, beta2, eps;
+  float loss_scale;
+  float* out_score;
+  float* out_loss;
+  float* out_R;
+  float* out_T;
+  float* out_grad;
+  float* out_cd;
+};
+
+constexpr int kAccN = 13;      // sum sqrt(d), G[3], (G p^T)[9]
+constexpr int kAccStride = 16;
+
+struct Smem {
+  float4* tgt;     // [Mpad]
+  float4* mov;     // [Npad]
+  double* state;   // [24]
+  float* pose;     // [12] R row-major, T
+  float* acc;      // [8][kAccStride]   slot = metric*2 + dir
+  float* red;      // [NW][kAccStride]
+  unsigned* hist;  // [256]
+  int* ctl;        // [8 + NW]
+};
+
+__host__ __device__ inline size_t smem_bytes(int N, int M, int block) {
+  const int npad = (N + kSub - 1) / kSub * kSub, mpad = (M + kSub - 1) / kSub * kSub;
+  const int nw = block / 64;
+  return (size_t)(npad + mpad) * 16 + 24 * 8 + 12 * 4 + 8 * kAccStride * 4 + (size_t)nw * kAccStride * 4 + 256 * 4 +
+         (8 + nw) * 4 + 64;
+}
+
+__device__ inline Smem carve(unsigned char* base, int N, int M, int block) {
+  const int npad = (N + kSub - 1) / kSub * kSub, mpad = (M + kSub - 1) / kSub * kSub;
+  const int nw = block / 64;
+  Smem s;
+  s.tgt = reinterpret_cast<float4*>(base);
+  s.mov = s.tgt + mpad;
+  s.state = reinterpret_cast<double*>(s.mov + npad);
+  s.pose = reinterpret_cast<float*>(s.state + 24);
+  s.acc = s.pose + 12;
+  s.red = s.acc + 8 * kAccStride;
+  s.hist = reinterpret_cast<unsigned*>(s.red + nw * kAccStride);
+  s.ctl = reinterpret_cast<int*>(s.hist + 256);
+  return s;
+}
+
+// ------------------------------------------------------------------------------------------------
+// The brute-force sweep: for each of this lane's Q queries, min over all references of the NMET
+// squared distances, plus the id of the 32-reference sub-tile that produced each minimum.
+// ------------------------------------------------------------------------------------------------
+template <int Q, int NMET>
+__device__ __forceinline__ void sweep(const float4* __restrict__ refs, int ntile, const float (&qx)[Q],
+                                      const float (&qy)[Q], const float (&qz)[Q], float (&best)[Q][NMET],
+                                      int (&btile)[Q][NMET]) {
+#pragma unroll
+  for (int k = 0; k < Q; ++k)
+#pragma unroll
+    for (int m = 0; m < NMET; ++m) {
+      best[k][m] = INFINITY;
+      btile[k][m] = 0;
+    }
+  for (int t = 0; t < ntile; ++t) {
+    float tm[Q][NMET];
+#pragma unroll
+    for (int k = 0; k < Q; ++k)
+#pragma unroll
+      for (int m = 0; m < NMET; ++m) tm[k][m] = INFINITY;
+    const float4* rp = refs + t * kSub;
+#pragma unroll 4
+    for (int j = 0; j < kSub; j += 2) {
+      const float4 a = rp[j], c = rp[j + 1];
+      // keep .w "used" so the loads stay ds_read_b128 (4 LDS cycles) instead of ds_read_b96 (8)
+      asm volatile("" ::"v"(a.w), "v"(c.w));
+#pragma unroll
+      for (int k = 0; k < Q; ++k) {
+        const float ax = a.x - qx[k], ay = a.y - qy[k], az = a.z - qz[k];
+        const float cx = c.x - qx[k], cy = c.y - qy[k], cz = c.z - qz[k];
+        if constexpr (NMET == 4) {
+          const float axx = ax * ax, ayy = ay * ay, cxx = cx * cx, cyy = cy * cy;
+          const float a3 = __builtin_fmaf(ay, ay, axx), c3 = __builtin_fmaf(cy, cy, cxx);   // z dropped
+          const float a1 = __builtin_fmaf(az, az, ayy), c1 = __builtin_fmaf(cz, cz, cyy);   // x dropped
+          const float a2 = __builtin_fmaf(az, az, axx), c2 = __builtin_fmaf(cz, cz, cxx);   // y dropped
+          const float a0 = __builtin_fmaf(az, az, a3), c0 = __builtin_fmaf(cz, cz, c3);     // full
+          tm[k][0] = min3f(tm[k][0], a0, c0);
+          tm[k][1] = min3f(tm[k][1], a1, c1);
+          tm[k][2] = min3f(tm[k][2], a2, c2);
+          tm[k][3] = min3f(tm[k][3], a3, c3);
+        } else {
+          tm[k][0] = min3f(tm[k][0], metric_sqdist<0>(ax, ay, az), metric_sqdist<0>(cx, cy, cz));
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < Q; ++k)
+#pragma unroll
+      for (int m = 0; m < NMET; ++m) {
+        const bool lt = tm[k][m] < best[k][m];   // strict: earlier sub-tile keeps ties (lowest index wins)
+        best[k][m] = lt ? tm[k][m] : best[k][m];
+        btile[k][m] = lt ? t : btile[k][m];
+      }
+  }
+}
+
+// Sum NV per-thread values over the workgroup into out[0..NV) (LDS).
+template <int BLOCK, int NV>
+__device__ __forceinline__ void block_sum(float (&v)[NV], float* red, float* out) {
+  constexpr int NW = BLOCK / 64;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) v[i] = wave_sum(v[i]);
+  __syncthreads();
+  if (lane == 0) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) red[wave * kAccStride + i] = v[i];
+  }
+  __syncthreads();
+  if (threadIdx.x < NV) {
+    float a = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) a += red[w * kAccStride + threadIdx.x];
+    out[threadIdx.x] = a;
+  }
+}
+
+// Exact selection of the `ksel` smallest of the BLOCK*Q keys (fp32 bit patterns of non-negative
+// distances; 0xFFFFFFFF marks "not a point").  4-pass 8-bit radix select, LDS histogram.
+// Ties at the threshold are taken in (thread, k) order -- torch.topk leaves tie order unspecified.
+template <int BLOCK, int Q>
+__device__ __forceinline__ void select_smallest(const unsigned (&key)[Q], int ksel, unsigned* hist, int* ctl,
+                                                bool (&sel)[Q]) {
+  constexpr int NW = BLOCK / 64;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  unsigned prefix = 0u, mask = 0u;
+  int remaining = ksel, neq = 0;
+#pragma unroll 1
+  for (int pass = 0; pass < 4; ++pass) {
+    const int shift = 24 - 8 * pass;
+    __syncthreads();
+    for (int i = tid; i < 256; i += BLOCK) hist[i] = 0u;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < Q; ++k)
+      if ((key[k] & mask) == prefix) atomicAdd(&hist[(key[k] >> shift) & 255u], 1u);
+    __syncthreads();
+    if (wave == 0) {
+      const int h0 = (int)hist[4 * lane + 0], h1 = (int)hist[4 * lane + 1], h2 = (int)hist[4 * lane + 2],
+                h3 = (int)hist[4 * lane + 3];
+      const int tot = h0 + h1 + h2 + h3;
+      int c = wave_incl_scan_i(tot) - tot;
+      const int hh[4] = {h0, h1, h2, h3};
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        if (c < remaining && remaining <= c + hh[b]) {
+          ctl[0] = 4 * lane + b;
+          ctl[1] = c;
+          ctl[2] = hh[b];
+        }
+        c += hh[b];
+      }
+    }
+    __syncthreads();
+    prefix |= (unsigned)ctl[0] << shift;
+    mask |= 255u << shift;
+    remaining -= ctl[1];
+    neq = ctl[2];
+  }
+  if (neq == remaining) {
+#pragma unroll
+    for (int k = 0; k < Q; ++k) sel[k] = key[k] <= prefix;
+  } else {
+    int e = 0;
+#pragma unroll
+    for (int k = 0; k < Q; ++k) e += (key[k] == prefix) ? 1 : 0;
+    const int incl = wave_incl_scan_i(e);
+    __syncthreads();
+    if (lane == 63) ctl[8 + wave] = incl;
+    __syncthreads();
+    int rank = incl - e;
+    for (int w = 0; w < NW; ++w) rank += (w < wave) ? ctl[8 + w] : 0;
+#pragma unroll
+    for (int k = 0; k < Q; ++k) {
+      const bool eq = key[k] == prefix;
+      sel[k] = key[k] < prefix || (eq && rank < remaining);
+      rank += eq ? 1 : 0;
+    }
+  }
+}
+
+// Epilogue of one sweep for metric MET.
+//   DIR == 1: queries are this lane's moved points (count = N), references the target cloud.
+//   DIR == 0: queries are this lane's target points (count = M), references the moved cloud.
+// Recovers the exact NN, selects the ksel smallest distances, and reduces
+//   S = sum sqrt(d),  G = sum c,  GP = sum c p^T,   c = mask * (moved - target) / sqrt(d),  p = un-moved source point
+// over the selection into acc_out[0..13).
+template <int BLOCK, int Q, int MET, int DIR>
+__device__ __forceinline__ void epilogue_metric(const Smem& sm, const float4* __restrict__ refs, const float (&qx)[Q],
+                                                const float (&qy)[Q], const float (&qz)[Q], const float (&bestm)[Q],
+                                                const int (&btilem)[Q], int count, int ksel, const float (&px)[Q],
+                                                const float (&py)[Q], const float (&pz)[Q], float* acc_out) {
+  const int tid = threadIdx.x;
+  float nx[Q], ny[Q], nz[Q];
+  unsigned key[Q];
+  bool sel[Q];
+#pragma unroll
+  for (int k = 0; k < Q; ++k) {
+    const float4* rp = refs + btilem[k] * kSub;
+    const float bd = bestm[k];
+    int jb = 0;
+#pragma unroll 4
+    for (int j = kSub - 1; j >= 0; --j) {   // descending: the lowest matching index is kept
+      const float4 r = rp[j];
+      const float d = metric_sqdist<MET>(r.x - qx[k], r.y - qy[k], r.z - qz[k]);
+      jb = (d == bd) ? j : jb;
+    }
+    const float4 nn = rp[jb];
+    nx[k] = nn.x; ny[k] = nn.y; nz[k] = nn.z;
+    const bool valid = (k * BLOCK + tid) < count;
+    key[k] = valid ? __float_as_uint(bd) : 0xFFFFFFFFu;
+    sel[k] = valid;
+  }
+  if (ksel < count) select_smallest<BLOCK, Q>(key, ksel, sm.hist, sm.ctl, sel);
+
+  float acc[kAccN];
+#pragma unroll
+  for (int i = 0; i < kAccN; ++i) acc[i] = 0.f;
+  float R[9], T[3];
+  if constexpr (DIR == 0) {
+#pragma unroll
+    for (int i = 0; i < 9; ++i) R[i] = sm.pose[i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) T[i] = sm.pose[9 + i];
+  }
+#pragma unroll
+  for (int k = 0; k < Q; ++k) {
+    if (sel[k]) {
+      const float s = sqrtf(bestm[k]);
+      const float inv = 1.0f / s;   // d == 0 -> inf, and 0*inf = NaN below, as torch's sqrt backward gives
+      float dx, dy, dz, sx, sy, sz;
+      if constexpr (DIR == 1) {
+        dx = qx[k] - nx[k]; dy = qy[k] - ny[k]; dz = qz[k] - nz[k];
+        sx = px[k]; sy = py[k]; sz = pz[k];
+      } else {
+        dx = nx[k] - qx[k]; dy = ny[k] - qy[k]; dz = nz[k] - qz[k];
+        const float ux = nx[k] - T[0], uy = ny[k] - T[1], uz = nz[k] - T[2];
+        sx = R[0] * ux + R[3] * uy + R[6] * uz;   // R^T (p' - T)
+        sy = R[1] * ux + R[4] * uy + R[7] * uz;
+        sz = R[2] * ux + R[5] * uy + R[8] * uz;
+      }
+      if constexpr (MET == 1) dx = 0.f;
+      if constexpr (MET == 2) dy = 0.f;
+      if constexpr (MET == 3) dz = 0.f;
+      const float cx = dx * inv, cy = dy * inv, cz = dz * inv;
+      acc[0] += s;
+      acc[1] += cx; acc[2] += cy; acc[3] += cz;
+      acc[4] += cx * sx; acc[5] += cx * sy; acc[6] += cx * sz;
+      acc[7] += cy * sx; acc[8] += cy * sy; acc[9] += cy * sz;
+      acc[10] += cz * sx; acc[11] += cz * sy; acc[12] += cz * sz;
+    }
+  }
+  block_sum<BLOCK, kAccN>(acc, sm.red, acc_out);
+}
+
+template <int BLOCK, int Q, int NMET, int DIR>
+__device__ __forceinline__ void epilogue(const Smem& sm, const float4* __restrict__ refs, const float (&qx)[Q],
+                                         const float (&qy)[Q], const float (&qz)[Q], const float (&best)[Q][NMET],
+                                         const int (&btile)[Q][NMET], int count, int k_full, int k_view,
+                                         const float (&px)[Q], const float (&py)[Q], const float (&pz)[Q]) {
+  float bm[Q];
+  int bt[Q];
+#define HOUV_EPI(MET)                                                                                              \
+  {                                                                                                                \
+    _Pragma("unroll") for (int k = 0; k < Q; ++k) {                                                                \
+      bm[k] = best[k][MET];                                                                                        \
+      bt[k] = btile[k][MET];                                                                                       \
+    }                                                                                                              \
+    epilogue_metric<BLOCK, Q, MET, DIR>(sm, refs, qx, qy, qz, bm, bt, count, (MET == 0) ? k_full : k_view, px, py, \
+                                        pz, sm.acc + (MET * 2 + DIR) * kAccStride);                                \
+  }
+  HOUV_EPI(0)
+  if constexpr (NMET == 4) {
+    HOUV_EPI(1)
+    HOUV_EPI(2)
+    HOUV_EPI(3)
+  }
+#undef HOUV_EPI
+}
+
+template <int BLOCK, int Q, int NMET>
+__global__ __launch_bounds__(BLOCK, 4) void solve_kernel(SolveArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int N = a.N, M = a.M;
+  const Smem sm = carve(smem_raw, N, M, BLOCK);
+  const int tid = threadIdx.x;
+  const int ninst = a.P * a.K;
+  // XCD-aware placement: workgroups b and b+8 share an XCD (and its L2), so give each XCD a contiguous
+  // range of hypotheses -> the K restarts of one pair read the pair's clouds through ONE L2.
+  int inst = blockIdx.x;
+  if ((ninst & 7) == 0) inst = (blockIdx.x & 7) * (ninst >> 3) + (blockIdx.x >> 3);
+  const int pair = inst / a.K;
+  const float* __restrict__ src = a.src + (size_t)pair * N * 3;
+  const float* __restrict__ tgt = a.tgt + (size_t)pair * M * 3;
+  const int npad = (N + kSub - 1) / kSub * kSub, mpad = (M + kSub - 1) / kSub * kSub;
+  const float4 pad4 = make_float4(INFINITY, INFINITY, INFINITY, 0.f);   // padding references never win
+
+  for (int j = tid; j < mpad; j += BLOCK) sm.tgt[j] = (j < M) ? make_float4(tgt[j * 3], tgt[j * 3 + 1], tgt[j * 3 + 2], 0.f) : pad4;
+  for (int j = N + tid; j < npad; j += BLOCK) sm.mov[j] = pad4;
+  if (tid < 24) sm.state[tid] = a.state[(size_t)inst * 24 + tid];
+  __syncthreads();
+  if (tid == 0) {
+    float p[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) p[k] = (float)sm.state[k];
+    Pose f;
+    pose_forward(p, a.angle_base, a.trans_mode, f);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) sm.pose[k] = f.R[k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) sm.pose[9 + k] = f.T[k];
+  }
+  __syncthreads();
+
+#pragma unroll 1
+  for (int it = 0; it < a.n_iters; ++it) {
+    float best[Q][NMET];
+    int btile[Q][NMET];
+    {
+      // ---- move this lane's source points, publish them as references for sweep B ----
+      float sx[Q], sy[Q], sz[Q], mx[Q], my[Q], mz[Q];
+      float R[9], T[3];
+#pragma unroll
+      for (int i = 0; i < 9; ++i) R[i] = sm.pose[i];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) T[i] = sm.pose[9 + i];
+#pragma unroll
+      for (int k = 0; k < Q; ++k) {
+        const int i = k * BLOCK + tid;
+        const bool ok = i < N;
+        sx[k] = ok ? src[i * 3 + 0] : 0.f;
+        sy[k] = ok ? src[i * 3 + 1] : 0.f;
+        sz[k] = ok ? src[i * 3 + 2] : 0.f;
+        // src @ R^T + T (houv.py:102)
+        mx[k] = __builtin_fmaf(sz[k], R[2], __builtin_fmaf(sy[k], R[1], sx[k] * R[0])) + T[0];
+        my[k] = __builtin_fmaf(sz[k], R[5], __builtin_fmaf(sy[k], R[4], sx[k] * R[3])) + T[1];
+        mz[k] = __builtin_fmaf(sz[k], R[8], __builtin_fmaf(sy[k], R[7], sx[k] * R[6])) + T[2];
+        if (ok) sm.mov[i] = make_float4(mx[k], my[k], mz[k], 0.f);
+      }
+      __syncthreads();
+      // ---- sweep A: moved -> target ----
+      sweep<Q, NMET>(sm.tgt, mpad / kSub, mx, my, mz, best, btile);
+      epilogue<BLOCK, Q, NMET, 1>(sm, sm.tgt, mx, my, mz, best, btile, N, a.k_full, a.k_view, sx, sy, sz);
+    }
+    {
+      // ---- sweep B: target -> moved ----
+      float tx[Q], ty[Q], tz[Q];
+#pragma unroll
+      for (int k = 0; k < Q; ++k) {
+        const int i = k * BLOCK + tid;
+        const float4 v = (i < M) ? sm.tgt[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        tx[k] = v.x; ty[k] = v.y; tz[k] = v.z;
+      }
+      sweep<Q, NMET>(sm.mov, npad / kSub, tx, ty, tz, best, btile);
+      epilogue<BLOCK, Q, NMET, 0>(sm, sm.mov, tx, ty, tz, best, btile, M, a.k_full, a.k_view, tx, ty, tz);
+    }
+    __syncthreads();
+
+    // ---- per-hypothesis scalar tail: loss, closed-form gradient, Adam, next pose ----
+    if (tid == 0) {
+      float p[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) p[k] = (float)sm.state[k];
+      Pose f;
+      pose_forward(p, a.angle_base, a.trans_mode, f);
+      float cd[NMET][2], val[NMET];
+      int pick[NMET];
+      float gT[3] = {0.f, 0.f, 0.f}, Mm[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      float loss = 0.f;
+      bool bad = false;
+#pragma unroll
+      for (int m = 0; m < NMET; ++m) {
+        const float kk = (float)((m == 0) ? a.k_full : a.k_view);
+        cd[m][0] = sm.acc[(m * 2 + 0) * kAccStride] / kk;   // over target points   (calc_cd_percent's 1st output)
+        cd[m][1] = sm.acc[(m * 2 + 1) * kAccStride] / kk;   // over moved points    (2nd output)
+        // torch.min(cat([first, second])): first wins ties; NaN propagates
+        pick[m] = (cd[m][0] <= cd[m][1]) ? 0 : 1;
+        val[m] = cd[m][pick[m]];
+        if (cd[m][0] != cd[m][0] || cd[m][1] != cd[m][1]) { val[m] = NAN; bad = true; }
+        const float w = ((m == 0) ? 6.0f : 1.0f) * a.loss_scale / kk;
+        const float* ac = sm.acc + (m * 2 + pick[m]) * kAccStride;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) gT[i] += w * ac[1 + i];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) Mm[i] += w * ac[4 + i];
+      }
+      loss = val[0] * 6.0f;                                  // houv.py:222 / train_utils.py:433
+      if constexpr (NMET == 4) loss = loss + (val[1] + val[2] + val[3]);
+      if (bad) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) gT[i] = NAN;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) Mm[i] = NAN;
+      }
+      float g[8];
+      pose_backward(f, a.trans_mode, gT, Mm, g);
+      if (it == a.n_iters - 1) {
+        // outputs of the LAST forward (houv.py:134-136: the final step is never observed)
+        if (a.out_score) a.out_score[inst] = val[0];
+        if (a.out_loss) a.out_loss[inst] = loss;
+        if (a.out_R)
+          for (int k = 0; k < 9; ++k) a.out_R[(size_t)inst * 9 + k] = f.R[k];
+        if (a.out_T)
+          for (int k = 0; k < 3; ++k) a.out_T[(size_t)inst * 3 + k] = f.T[k];
+        if (a.out_grad)
+          for (int k = 0; k < 8; ++k) a.out_grad[(size_t)inst * 8 + k] = g[k];
+        if (a.out_cd)
+          for (int m = 0; m < 4; ++m)
+            for (int d = 0; d < 2; ++d) a.out_cd[(size_t)inst * 8 + m * 2 + d] = (m < NMET) ? cd[m < NMET ? m : 0][d] : 0.f;
+      }
+      const int step = a.steps_done + it + 1;
+      if (a.f64_params) {
+        for (int k = 0; k < 8; ++k)
+          adam_step<double>(sm.state[k], sm.state[8 + k], sm.state[16 + k], (double)g[k], step, a.lr, a.beta1, a.beta2, a.eps);
+      } else {
+        for (int k = 0; k < 8; ++k) {
+          float pp = (float)sm.state[k], mm = (float)sm.state[8 + k], vv = (float)sm.state[16 + k];
+          adam_step<float>(pp, mm, vv, g[k], step, a.lr, a.beta1, a.beta2, a.eps);
+          sm.state[k] = pp; sm.state[8 + k] = mm; sm.state[16 + k] = vv;
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) p[k] = (float)sm.state[k];
+      pose_forward(p, a.angle_base, a.trans_mode, f);
+#pragma unroll
+      for (int k = 0; k < 9; ++k) sm.pose[k] = f.R[k];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) sm.pose[9 + k] = f.T[k];
+    }
+    __syncthreads();
+  }
+  if (tid < 24) a.state[(size_t)inst * 24 + tid] = sm.state[tid];
+}
+
+template <int BLOCK, int Q>
+int launch(const SolveArgs& a, int use_views, hipStream_t s) {
+  const size_t bytes = smem_bytes(a.N, a.M, BLOCK);
+  const int grid = a.P * a.K;
+  hipError_t e;
+  if (use_views) {
+    e = hipFuncSetAttribute((const void*)solve_kernel<BLOCK, Q, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) { set_error("houv_solve_iterate: cannot reserve %zu B of LDS: %s", bytes, hipGetErrorString(e)); return 0; }
+    solve_kernel<BLOCK, Q, 4><<<grid, BLOCK, bytes, s>>>(a);
+  } else {
+    e = hipFuncSetAttribute((const void*)solve_kernel<BLOCK, Q, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) { set_error("houv_solve_iterate: cannot reserve %zu B of LDS: %s", bytes, hipGetErrorString(e)); return 0; }
+    solve_kernel<BLOCK, Q, 1><<<grid, BLOCK, bytes, s>>>(a);
+  }
+  return check_launch("houv_solve_iterate") ? 1 : 0;
+}
+
+}  // namespace
+}  // namespace houv
+
+extern "C" int houv_solve_iterate(const float* src, const float* tgt, int P, int N, int M, int K, double* state,
+                                  int steps_done, int n_iters, int angle_base, int trans_mode, int use_views,
+                                  int f64_params, int k_full, int k_view, double lr, double beta1, double beta2,
+                                  double eps, float loss_scale, float* out_score, float* out_loss, float* out_R,
+                                  float* out_T, float* out_grad, float* out_cd, void* stream) {
+  using namespace houv;
+  if (P < 0 || N <= 0 || M <= 0 || K <= 0 || n_iters <= 0 || steps_done < 0 || angle_base < 0 || angle_base > 3 ||
+      trans_mode < 0 || trans_mode > 1) {
+    set_error("houv_solve_iterate: bad argument P=%d N=%d M=%d K=%d n_iters=%d steps_done=%d base=%d trans_mode=%d", P,
+              N, M, K, n_iters, steps_done, angle_base, trans_mode);
+    return 0;
+  }
+  if (P == 0) return 1;
+  if (!src || !tgt || !state) {
+    set_error("houv_solve_iterate: null pointer");
+    return 0;
+  }
+  // topk(k) over a direction with fewer than k points raises in the reference (model_utils_completion.py:91-92)
+  const int kv = use_views ? k_view : 1;
+  if (k_full < 1 || k_full > N || k_full > M || kv < 1 || kv > N || kv > M) {
+    set_error("houv_solve_iterate: top-k size out of range (k_full=%d k_view=%d N=%d M=%d)", k_full, k_view, N, M);
+    return 0;
+  }
+  if ((long long)P * K > 0x7fffffffLL) {
+    set_error("houv_solve_iterate: too many hypotheses");
+    return 0;
+  }
+  SolveArgs a{src, tgt, P, N, M, K, state, steps_done, n_iters, angle_base, trans_mode, f64_params, k_full, k_view,
+              lr, beta1, beta2, eps, loss_scale, out_score, out_loss, out_R, out_T, out_grad, out_cd};
+  hipStream_t s = (hipStream_t)stream;
+  const int mx = N > M ? N : M;
+  if (smem_bytes(N, M, 1024) > 160 * 1024) {
+    set_error("houv_solve_iterate: clouds of %d + %d points do not fit in 160 KiB of LDS", N, M);
+    return 0;
+  }
+  if (mx <= 256) return launch<256, 1>(a, use_views, s);
+  if (mx <= 512) return launch<256, 2>(a, use_views, s);
+  if (mx <= 1024) return launch<256, 4>(a, use_views, s);
+  if (mx <= 2048) return launch<512, 4>(a, use_views, s);
+  if (mx <= 4096) return launch<1024, 4>(a, use_views, s);
+  set_error("houv_solve_iterate: clouds larger than 4096 points are not supported (N=%d M=%d)", N, M);
+  return 0;
+}

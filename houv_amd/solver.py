@@ -1,0 +1,103 @@
+"""Host driver of the fused HOUV loop: parameter initialisation (host numpy, exactly as the reference draws
+it), chunked launches of houv_solve_iterate, and the best-of-K + angle-window retry logic shared by
+``solve_model`` (registration/models/houv.py:142-206) and ``solve`` (registration/train_utils.py:467-572)."""
+import numpy as np
+import torch
+
+from . import ops
+
+RETRY_THRESHOLD = 0.030      # houv.py:156, train_utils.py:494 (strict >)
+ITERS_PER_LAUNCH = 50        # bound single-launch duration; state round-trips through HBM (192 B/hypothesis)
+
+# the 26 non-zero {-1,0,1}^3 axes in the reference's loop order (houv.py:44-51)
+LATTICE_AXES = np.array([(x, y, z) for x in (-1, 0, 1) for y in (-1, 0, 1) for z in (-1, 0, 1)
+                         if (x, y, z) != (0, 0, 0)], dtype=np.float64)
+
+
+def houv_init_params(n_inst, seed=2021):
+    """HOUV.reset_weight (houv.py:40-61): re-seed numpy before every draw; rows 0..25 of V are the lattice
+    axes (n_inst < 26 raises, as the reference's unchecked assignment does).  Returns float64 [n,8] whose
+    entries are the reference's float32 values."""
+    np.random.seed(seed)
+    V = np.random.randn(n_inst, 3)
+    if n_inst < 26:
+        raise IndexError(f"index {n_inst} is out of bounds for axis 0 with size {n_inst}")   # houv.py:50
+    V[:26] = LATTICE_AXES
+    np.random.seed(seed)
+    a = np.random.randn(n_inst, 1)
+    np.random.seed(seed)
+    c = np.random.randn(n_inst, 3)
+    np.random.seed(seed)
+    s = np.random.randn(n_inst, 1)
+    return np.concatenate([V, a, c, s], axis=1).astype(np.float32).astype(np.float64)
+
+
+def solve_twin_init_params(n_inst):
+    """getPredict_angle (train_utils.py:381-386): float64 draws from the GLOBAL numpy RNG in the order
+    V, angle, tran_c, tran_s, angle_XYZ (the last is never used but advances the generator)."""
+    V = np.random.randn(n_inst, 3)
+    a = np.random.randn(n_inst, 1)
+    c = np.random.randn(n_inst, 3)
+    s = np.random.randn(n_inst, 1)
+    np.random.randn(n_inst, 3)
+    return np.concatenate([V, a, c, s], axis=1)
+
+
+def run_stage(src, tgt, params, K, n_iters, *, angle_base, trans_mode, use_views, f64_params, lr,
+              iters_per_launch=None, want_grad=False, want_cd=False, alpha=0.5):
+    """Run ``n_iters`` optimisation iterations for P*K hypotheses.  params: float64 [P*K,8] (numpy or tensor).
+    Returns (out dict of the last forward, state tensor [P*K,24] fp64 after n_iters Adam steps)."""
+    if n_iters < 1:
+        raise ValueError("num_epochs must be >= 1 (the reference reads the last iteration's outputs)")
+    src = src.contiguous().float()
+    tgt = tgt.contiguous().float()
+    P, N, _ = src.shape
+    dev = src.device
+    n = P * K
+    state = torch.zeros((n, 24), dtype=torch.float64, device=dev)
+    p = torch.as_tensor(params, dtype=torch.float64)
+    if tuple(p.shape) != (n, 8):
+        raise ValueError(f"params must be [{n},8]")
+    state[:, :8] = p.to(dev)
+    k_full = int(N * alpha)            # model_utils_completion.py:85-86 with percent = alpha
+    k_view = int(N * 1)
+    step = iters_per_launch or ITERS_PER_LAUNCH
+    done, out = 0, None
+    while done < n_iters:
+        it = min(step, n_iters - done)
+        last = done + it == n_iters
+        out = ops.solve_iterate(src, tgt, state, K, steps_done=done, n_iters=it, angle_base=angle_base,
+                                trans_mode=trans_mode, use_views=use_views, f64_params=f64_params, k_full=k_full,
+                                k_view=k_view, lr=lr, loss_scale=1.0 / n, want_grad=want_grad and last,
+                                want_cd=want_cd and last)
+        done += it
+    return out, state
+
+
+def best_of_k_with_retry(stage_fn, src, tgt):
+    """houv.py:152-197 / train_utils.py:488-545.  ``stage_fn(src, tgt, base) -> (score[B,K], R[B,K,3,3], T[B,K,3])``.
+    Base-0 stage; pairs whose best score is > 0.030 are re-solved in the 45-90/90-135/135-180 degree windows
+    and replaced where strictly better.  Returns ans[B,4,4] (row 3 left all-zero, as the reference leaves it),
+    score, and the retried pair indices.  One host sync per stage (the retry set is data dependent)."""
+    B = src.shape[0]
+    score, R, T = stage_fn(src, tgt, 0)
+    best, _ = score.topk(1, dim=1, largest=False, sorted=True)          # NaN hypotheses sort last
+    retry = torch.nonzero(best[:, 0] > RETRY_THRESHOLD).reshape(-1)
+    if retry.numel() > 0:
+        s_add, t_add = src[retry], tgt[retry]
+        for base in range(1, 4):
+            score_a, R_a, T_a = stage_fn(s_add, t_add, base)
+            best_a, _ = score_a.topk(1, dim=1, largest=False, sorted=True)
+            flag = torch.nonzero((best_a < best[retry]).reshape(-1)).reshape(-1)
+            ge = retry[flag]
+            R[ge] = R_a[flag]
+            score[ge] = score_a[flag]
+            T[ge] = T_a[flag]
+            best[ge] = best_a[flag]
+    _, k = score.topk(1, dim=1, largest=False, sorted=True)
+    pick = k[:, 0]
+    rows = torch.arange(B, device=score.device)
+    ans = torch.zeros((B, 4, 4), dtype=torch.float32, device=score.device)
+    ans[:, :3, :3] = R[rows, pick]
+    ans[:, :3, 3] = T[rows, pick]
+    return ans, score, retry

@@ -1,0 +1,104 @@
+/* houv_hip.h -- C ABI of libhouv_hip.so: the MI355X (gfx950) HOUV registration hot path.
+ *
+ * This is the drop-in boundary.  Every entry point replaces one interface of the reference
+ * (Dizzy-cell/HOUV; paths relative to the reference root) and keeps its conventions:
+ *   - the CALLER allocates every buffer; nothing is allocated or freed in here;
+ *   - all pointers are DEVICE pointers to contiguous row-major arrays (fp32 / int32 / fp64 as
+ *     declared) on the current device, unless a parameter says "host";
+ *   - work is enqueued on `stream` (a hipStream_t passed as void*; NULL = the null stream) and
+ *     the call returns without synchronising;
+ *   - return value 1 = enqueued OK, 0 = error (message via houv_last_error()); this is the
+ *     reference's own convention (utils/metrics/CD/chamfer3D/chamfer3D.cu:145-153).
+ *
+ * No torch types appear in any signature.
+ */
+#ifndef HOUV_HIP_H_
+#define HOUV_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HOUV_ABI_VERSION 1
+
+/* ABI version of the loaded library (== HOUV_ABI_VERSION). */
+int houv_abi_version(void);
+
+/* Thread-local text of the last error returned by any call below ("" if none). */
+const char* houv_last_error(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Chamfer nearest-neighbour op.
+ * Replaces: pybind `chamfer_3D.forward` -> chamfer_cuda_forward
+ *           (utils/metrics/CD/chamfer3D/chamfer_cuda.cpp:17-19,31; chamfer3D.cu:136-154; kernel :12-134).
+ *   dist1[b,i] = min_j |xyz1[b,i]-xyz2[b,j]|^2   idx1[b,i] = argmin_j (lowest j on ties)
+ *   dist2[b,j] = min_i |xyz2[b,j]-xyz1[b,i]|^2   idx2[b,j] = argmin_i
+ * fp32 direct-difference arithmetic d = fma(dz,dz,fma(dy,dy,dx*dx)).
+ * xyz1[B,N,3] xyz2[B,M,3] dist1[B,N] dist2[B,M] idx1[B,N] idx2[B,M].  N or M == 0 is an error. */
+int houv_chamfer_forward(const float* xyz1, const float* xyz2, int B, int N, int M,
+                         float* dist1, float* dist2, int32_t* idx1, int32_t* idx2, void* stream);
+
+/* Replaces: pybind `chamfer_3D.backward` -> chamfer_cuda_backward
+ *           (chamfer_cuda.cpp:22-26,32; chamfer3D.cu:176-195; kernel :155-174).
+ * ACCUMULATES into gradxyz1[B,N,3] / gradxyz2[B,M,3], which the caller must have zero-filled
+ * (dist_chamfer_3D.py:56-60), exactly like the reference:
+ *   g = 2*graddist1[b,i]; gradxyz1[b,i] += g (x1_i - x2_idx1);  gradxyz2[b,idx1] -= same;  and symmetrically. */
+int houv_chamfer_backward(const float* xyz1, const float* xyz2, int B, int N, int M,
+                          const float* graddist1, const float* graddist2,
+                          const int32_t* idx1, const int32_t* idx2,
+                          float* gradxyz1, float* gradxyz2, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Kabsch rigid solve: 3x3 (weighted) covariance reduction + register-resident Jacobi SVD.
+ * Replaces: SVDHead.forward (registration/model_utils.py:220-255).
+ *   src, corr: [B,3,N] (channel-major like the reference); w: [B,1,N] or NULL.
+ *   R[B,3,3], t[B,3].  Centres by the UNWEIGHTED means; reflection fix on det<0. */
+int houv_kabsch(const float* src, const float* corr, const float* w_or_null, int B, int N,
+                float* R, float* t, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Fused HOUV optimisation loop.
+ * Replaces the body of predict_model (registration/models/houv.py:106-138) and of getPredict_angle
+ * (registration/train_utils.py:359-456): for every hypothesis (pair p, restart k) it runs
+ * `n_iters` x { pose from the 8 unconstrained scalars -> move the source cloud -> robust Chamfer
+ * loss (Predict_loss, houv.py:209-222) -> closed-form gradient -> Adam step } entirely on chip.
+ *
+ *   src[P,N,3], tgt[P,M,3]   the P pairs (NOT replicated K times)
+ *   state[P*K,24] fp64       per hypothesis: param[8] = (V0,V1,V2, a, c0,c1,c2, s), adam_m[8], adam_v[8];
+ *                            in/out.  With f64_params == 0 the values are fp32 numbers stored widened.
+ *   steps_done               Adam steps already applied to `state` (0 for a fresh stage)
+ *   n_iters                  iterations to run now (>= 1)
+ *   angle_base               0..3: rotation-angle window base*45deg .. base*45+45deg (houv.py:96)
+ *   trans_mode               0: sigma = sin(s pi)/8 + 1/8 (houv.py:99)   1: sigma = sin(s pi) (train_utils.py:404)
+ *   use_views                1: loss = 6 min_1 + three projected Chamfer terms (houv.py:222)
+ *                            0: loss = 6 min_1 (train_utils.py:433)
+ *   f64_params               0: fp32 parameters + fp32 Adam (HOUV module)   1: fp64 leaves + fp64 Adam (`solve` twin)
+ *   k_full, k_view           top-k sizes: int(N*0.5) and int(N*1) (model_utils_completion.py:85-86)
+ *   lr, beta1, beta2, eps    Adam hyper-parameters
+ *   loss_scale               d(objective)/d(per-hypothesis loss) = 1/(P*K) for `.mean()` (houv.py:124)
+ * Outputs (each may be NULL), all from the LAST forward pass, i.e. before the last Adam step
+ * (houv.py:134-136):
+ *   out_score[P*K] = min_1   out_loss[P*K]   out_R[P*K,9]   out_T[P*K,3]
+ *   out_grad[P*K,8]  d(objective)/d(param) of the last forward
+ *   out_cd[P*K,8]    the 8 Chamfer terms: metric m (0 = full, 1..3 = view dropping x,y,z) x
+ *                    direction (0: over target points, 1: over moved points) at [2*m+dir]
+ * Limits: (roundup32(N)+roundup32(M))*16 B + 8 KiB must fit in 160 KiB of LDS; K >= 1. */
+int houv_solve_iterate(const float* src, const float* tgt, int P, int N, int M, int K,
+                       double* state, int steps_done, int n_iters,
+                       int angle_base, int trans_mode, int use_views, int f64_params,
+                       int k_full, int k_view,
+                       double lr, double beta1, double beta2, double eps, float loss_scale,
+                       float* out_score, float* out_loss, float* out_R, float* out_T,
+                       float* out_grad, float* out_cd, void* stream);
+
+/* Pose only (HOUV.forward, houv.py:94-103): params fp32 [n,8] -> R[n,9], T[n,3]; if src != NULL
+ * also moved[n,N,3] = src[n,N,3] @ R^T + T. */
+int houv_pose_forward(const float* params, int n, int angle_base, int trans_mode,
+                      const float* src_or_null, int N, float* R, float* T, float* moved_or_null, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HOUV_HIP_H_ */

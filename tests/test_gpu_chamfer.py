@@ -1,0 +1,145 @@
+"""GPU parity of the Chamfer op (houv_chamfer_forward/backward through metrics.cd) against the oracle and the
+golden vectors captured from the reference.  Calls go through the C ABI (ctypes)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import houv_ref_cpu as orc  # noqa: E402
+
+T = torch.tensor
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "gpu tests need an MI355X"
+    return torch.device("cuda:0")
+
+
+def _cd(a, b, dev):
+    from houv_amd.metrics import cd
+    return cd()(a.to(dev), b.to(dev))
+
+
+def _assert_idx(i_gpu, i_ref, d_gpu, pts_q, pts_r):
+    """idx must be exact; where it is not, the two candidates must be tied to fp32 rounding (float64 check)."""
+    i_gpu = i_gpu.cpu().long().numpy(); i_ref = i_ref.long().numpy()
+    bad = np.argwhere(i_gpu != i_ref)
+    for b, i in bad:
+        q = pts_q[b, i].double(); r1 = pts_r[b, i_gpu[b, i]].double(); r2 = pts_r[b, i_ref[b, i]].double()
+        d1 = float(((q - r1) ** 2).sum()); d2 = float(((q - r2) ** 2).sum())
+        assert abs(d1 - d2) <= 2e-7 * max(d1, d2), f"idx mismatch not a tie: {d1} vs {d2}"
+    return len(bad)
+
+
+def test_golden_unit_test_shapes(golden, dev):
+    """The reference's own test case and bar (utils/metrics/CD/unit_test.py:15-33): idx exactly equal,
+    mean squared dist difference < 1e-8 -- on the reference's outputs for the same inputs."""
+    g = golden("g1_chamfer.npz")
+    d1, d2, i1, i2 = _cd(T(g["p1"]), T(g["p2"]), dev)
+    assert np.array_equal(i1.cpu().numpy(), g["idx1"]) and np.array_equal(i2.cpu().numpy(), g["idx2"])
+    assert ((d1.cpu().numpy() - g["dist1"]) ** 2).mean() + ((d2.cpu().numpy() - g["dist2"]) ** 2).mean() < 1e-8
+    np.testing.assert_allclose(d1.cpu().numpy(), g["dist1"], rtol=2e-5, atol=1e-7)   # fp32 direct vs f64 expanded form
+    np.testing.assert_allclose(d2.cpu().numpy(), g["dist2"], rtol=2e-5, atol=1e-7)
+    assert i1.dtype == torch.int32 and d1.dtype == torch.float32
+
+
+def test_golden_2048(golden, dev):
+    g = golden("g1_chamfer.npz")
+    a, b = T(g["big_a"]), T(g["big_b"])
+    d1, d2, i1, i2 = _cd(a, b, dev)
+    n_bad = _assert_idx(i1, T(g["big_idx1"]), d1, a, b) + _assert_idx(i2, T(g["big_idx2"]), d2, b, a)
+    assert n_bad <= 2
+    np.testing.assert_allclose(d1.cpu().numpy(), g["big_dist1"], rtol=1e-4, atol=1e-7)
+    np.testing.assert_allclose(d2.cpu().numpy(), g["big_dist2"], rtol=1e-4, atol=1e-7)
+
+
+@pytest.mark.parametrize("B,N,M", [(1, 1, 1), (3, 1, 70), (2, 33, 31), (2, 257, 64), (1, 300, 2049),
+                                   (2, 1000, 2000), (1, 4100, 513), (5, 512, 512)])
+def test_ragged_shapes_vs_oracle(dev, B, N, M):
+    gen = torch.Generator().manual_seed(B * 100003 + N * 17 + M)
+    a = torch.rand(B, N, 3, generator=gen) - 0.5
+    b = torch.rand(B, M, 3, generator=gen) - 0.5
+    d1, d2, i1, i2 = _cd(a, b, dev)
+    o1, o2, j1, j2 = orc.chamfer_nn_chunked(a, b, chunk=1)
+    assert _assert_idx(i1, j1, d1, a, b) + _assert_idx(i2, j2, d2, b, a) <= 1
+    np.testing.assert_allclose(d1.cpu().numpy(), o1.numpy(), rtol=1e-4, atol=1e-7)
+    np.testing.assert_allclose(d2.cpu().numpy(), o2.numpy(), rtol=1e-4, atol=1e-7)
+
+
+def test_ties_pick_lowest_index(dev):
+    """Duplicated reference points: the lowest index must win, across sub-tile (32) and LDS-tile (2048) borders."""
+    gen = torch.Generator().manual_seed(5)
+    base = torch.rand(1, 40, 3, generator=gen)
+    b = base.repeat(1, 60, 1)                     # 2400 refs: every point appears 60 times, copies 40 apart
+    a = base.clone()
+    d1, _, i1, _ = _cd(a, b, dev)
+    assert torch.equal(i1.cpu()[0].long(), torch.arange(40))
+    assert float(d1.abs().max()) == 0.0
+
+
+def test_backward_golden_and_closed_form(golden, dev):
+    g = golden("g1_chamfer.npz")
+    from houv_amd.metrics import cd
+    p1 = T(g["p1"]).to(dev)
+    p2 = T(g["p2"]).to(dev).requires_grad_(True)
+    d1, d2, _, _ = cd()(p1, p2)
+    torch.sum(d1).backward()                      # the reference's own loss (unit_test.py:19-20)
+    np.testing.assert_allclose(p2.grad.cpu().numpy(), g["grad_p2"], rtol=1e-4, atol=2e-6)
+    q1 = T(g["q1"]).to(dev).requires_grad_(True)
+    q2 = T(g["q2"]).to(dev).requires_grad_(True)
+    e1, e2, j1, j2 = cd()(q1, q2)
+    assert np.array_equal(j1.cpu().numpy(), g["j1"]) and np.array_equal(j2.cpu().numpy(), g["j2"])
+    ((e1 * T(g["w1"]).to(dev)).sum() + (e2 * T(g["w2"]).to(dev)).sum()).backward()
+    np.testing.assert_allclose(q1.grad.cpu().numpy(), g["grad_q1"], rtol=1e-4, atol=2e-6)
+    np.testing.assert_allclose(q2.grad.cpu().numpy(), g["grad_q2"], rtol=1e-4, atol=2e-6)
+
+
+def test_pybind_style_module_contract(dev):
+    """chamfer_3D.forward/backward keep the reference's positional signature, in-place outputs and return 1
+    (chamfer_cuda.cpp:17-33); backward accumulates into pre-zeroed buffers."""
+    from houv_amd.metrics import chamfer_3D
+    a = torch.rand(2, 50, 3, device=dev); b = torch.rand(2, 60, 3, device=dev)
+    d1 = torch.zeros(2, 50, device=dev); d2 = torch.zeros(2, 60, device=dev)
+    i1 = torch.zeros(2, 50, dtype=torch.int32, device=dev); i2 = torch.zeros(2, 60, dtype=torch.int32, device=dev)
+    assert chamfer_3D.forward(a, b, d1, d2, i1, i2) == 1
+    o1, o2, j1, j2 = orc.chamfer_nn(a.cpu(), b.cpu())
+    assert torch.equal(i1.cpu(), j1) and torch.equal(i2.cpu(), j2)
+    g1 = torch.zeros_like(a); g2 = torch.zeros_like(b)
+    gd1 = torch.ones(2, 50, device=dev); gd2 = torch.zeros(2, 60, device=dev)
+    assert chamfer_3D.backward(a, b, g1, g2, gd1, gd2, i1, i2) == 1
+    first = g1.clone()
+    assert chamfer_3D.backward(a, b, g1, g2, gd1, gd2, i1, i2) == 1
+    np.testing.assert_allclose(g1.cpu().numpy(), 2 * first.cpu().numpy(), rtol=1e-6)     # accumulation
+
+
+def test_errors_are_loud(dev):
+    from houv_amd import _lib
+    from houv_amd.metrics import cd
+    with pytest.raises(_lib.HouvHipError):
+        cd()(torch.rand(1, 4, 3), torch.rand(1, 4, 3))            # CPU tensors: no fallback
+    with pytest.raises(_lib.HouvHipError):
+        cd()(torch.rand(1, 0, 3, device=dev), torch.rand(1, 4, 3, device=dev))
+
+
+def test_full_size_properties(dev):
+    """BASELINE cfg2-sized batch slice (2048x2048): size-independent properties instead of a CPU oracle:
+    (i) dist equals the distance to the reported index; (ii) swapping the clouds swaps the outputs;
+    (iii) a cloud against itself gives dist 0 / idx identity; (iv) rigid motion invariance of idx."""
+    gen = torch.Generator().manual_seed(11)
+    B = 64
+    a = (torch.rand(B, 2048, 3, generator=gen) - 0.5).to(dev)
+    b = (torch.rand(B, 2048, 3, generator=gen) - 0.5).to(dev)
+    from houv_amd.metrics import cd
+    d1, d2, i1, i2 = cd()(a, b)
+    nn = torch.gather(b, 1, i1.long().unsqueeze(2).expand(-1, -1, 3))
+    np.testing.assert_allclose(((a - nn) ** 2).sum(2).cpu().numpy(), d1.cpu().numpy(), rtol=1e-5, atol=1e-9)
+    # brute-force check of a random subset of rows on the GPU with torch (float64)
+    sub = torch.randint(0, 2048, (64,), generator=gen).to(dev)
+    dm = ((a[:, sub].double().unsqueeze(2) - b.double().unsqueeze(1)) ** 2).sum(3)
+    np.testing.assert_allclose(dm.min(2)[0].float().cpu().numpy(), d1[:, sub].cpu().numpy(), rtol=1e-5, atol=1e-9)
+    e2, e1, j2, j1 = cd()(b, a)
+    assert torch.equal(e1, d1) and torch.equal(j1, i1) and torch.equal(e2, d2) and torch.equal(j2, i2)
+    s1, s2, k1, k2 = cd()(a, a)
+    assert float(s1.max()) == 0.0 and torch.equal(k1.cpu().long(), torch.arange(2048).expand(B, -1))

@@ -1,0 +1,80 @@
+"""GPU parity of houv_kabsch (SVDHead) and houv_pose_forward (HOUV.forward) against the golden vectors."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import houv_ref_cpu as orc  # noqa: E402
+
+T = torch.tensor
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def test_svdhead_golden(golden, dev):
+    from houv_amd.model_utils import SVDHead
+    g = golden("g7_svdhead.npz")
+    head = SVDHead()
+    R, t = head(T(g["src"]).to(dev), T(g["corr"]).to(dev))
+    np.testing.assert_allclose(R.cpu().numpy(), g["R"], atol=2e-5)
+    np.testing.assert_allclose(t.cpu().numpy(), g["t"], atol=2e-5)
+    Rw, tw = head(T(g["src"]).to(dev), T(g["corr"]).to(dev), T(g["w"]).to(dev))
+    np.testing.assert_allclose(Rw.cpu().numpy(), g["R_w"], atol=2e-5)
+    np.testing.assert_allclose(tw.cpu().numpy(), g["t_w"], atol=2e-5)
+    assert (torch.det(R) > 0.99).all()                        # reflection fix (model_utils.py:236-239)
+
+
+def test_kabsch_recovers_known_motion_full_size(dev):
+    """cfg2-sized property test: 16,384 samples x 2048 points, exact correspondences -> R,t recovered to 1e-5."""
+    B, N = 4096, 2048
+    gen = torch.Generator(device="cpu").manual_seed(0)
+    src = torch.randn(B, 3, N, generator=gen).to(dev)
+    q, _ = torch.linalg.qr(torch.randn(B, 3, 3, generator=gen))
+    q = q * torch.sign(torch.det(q)).view(B, 1, 1)
+    q = q.to(dev)
+    t0 = torch.randn(B, 3, 1, generator=gen).to(dev)
+    from houv_amd import ops
+    R, t = ops.kabsch(src, (q @ src + t0).contiguous())
+    np.testing.assert_allclose(R.cpu().numpy(), q.cpu().numpy(), atol=2e-5)
+    np.testing.assert_allclose(t.cpu().numpy(), t0[:, :, 0].cpu().numpy(), atol=2e-5)
+    ro, to = orc.kabsch_svd(src[:8].cpu(), (q @ src + t0)[:8].cpu())
+    np.testing.assert_allclose(R[:8].cpu().numpy(), ro.numpy(), atol=2e-5)
+
+
+def test_pose_forward_golden(golden, dev):
+    from houv_amd import ops
+    g = golden("g3_g4_params_forward.npz")
+    p = T(np.concatenate([g["V"], g["angle"], g["tran_c"], g["tran_s"]], 1)).to(dev)
+    for base in range(4):
+        R, Tt, moved = ops.pose_forward(p, base, 0, T(g["src"]).to(dev))
+        np.testing.assert_allclose(R.cpu().numpy(), g[f"R_b{base}"], atol=1e-6)
+        np.testing.assert_allclose(Tt.cpu().numpy(), g[f"T_b{base}"][:, 0], atol=1e-6)
+        np.testing.assert_allclose(moved.cpu().numpy(), g[f"moved_b{base}"], atol=1e-6)
+
+
+def test_houv_module_forward_matches_kernel_and_golden(golden, dev):
+    """HOUV.forward (differentiable torch mirror, houv.py:94-103) vs the reference's outputs."""
+    from houv_amd.models.houv import HOUV
+    g = golden("g3_g4_params_forward.npz")
+    net = HOUV(32, 0).to(dev)
+    for base in range(4):
+        net.reset_weight(32, base, seed=2021)
+        assert np.array_equal(net.V_c.detach().cpu().numpy(), g["V"])
+        st, R, Tt = net(T(g["src"]).to(dev))
+        np.testing.assert_allclose(st.detach().cpu().numpy(), g[f"moved_b{base}"], atol=1e-6)
+        np.testing.assert_allclose(R.detach().cpu().numpy(), g[f"R_b{base}"], atol=1e-6)
+        np.testing.assert_allclose(Tt.detach().cpu().numpy(), g[f"T_b{base}"], atol=1e-6)
+
+
+def test_metrics_golden(golden, dev):
+    from houv_amd.train_utils import rmse_loss, rotation_error, translation_error
+    g = golden("g8_metrics.npz")
+    Ta, Tb = T(g["Ta"]).to(dev), T(g["Tb"]).to(dev)
+    np.testing.assert_allclose(rotation_error(Ta[:, :3, :3], Tb[:, :3, :3]).cpu().numpy(), g["rot_err"], atol=2e-3)
+    np.testing.assert_allclose(translation_error(Ta[:, :3, 3], Tb[:, :3, 3]).cpu().numpy(), g["trans_err"], atol=1e-6)
+    np.testing.assert_allclose(rmse_loss(T(g["pts"]).to(dev), Ta, Tb).cpu().numpy(), g["rmse"], atol=1e-6)
