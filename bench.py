@@ -1,0 +1,216 @@
+#!/usr/bin/env python3
+"""bench.py -- HOUV registration throughput on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A "step" is one full `solve_model` pass (registration/models/houv.py:142-206: base-0 stage of K=64 restarts x 200
+Adam iterations, then the data-dependent retry stages at bases 1..3) over one batch of synthetic MVP-shaped pairs
+resident in HBM.  N=1 workload = BASELINE.json configs[1]: 2048x2048-point pairs, batch 256.  For N>1 every rank
+solves its own batch of the same size (weak scaling; pairs are independent, no data-path collective) and the ranks
+exchange the per-pair (R,t) with ONE RCCL all-gather per step.  Rank 0 prints one JSON line.
+
+Extra objects on the line:
+  roofline      the dominant kernel (houv::solve_kernel), timed live with HIP events on its launch stream
+  chamfer_op    the stand-alone Chamfer op at the same cloud size (BASELINE metric's "Chamfer HBM GB/s" half)
+  cpu_baseline  the CPU oracle (oracle/houv_ref_cpu.py, the reference's PyTorch-CPU formulation) on a bounded sample
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP32_PEAK_TFLOPS = 157.3     # MI355X fp32 vector == fp32-input MFMA peak (MI355X_MICROARCH.md, chip-level table)
+HBM_PEAK_GBPS = 8000.0
+FLOP_PER_EVAL = 8            # 3 sub + 1 mul + 2 fma per squared distance
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--pairs", type=int, default=256, help="pairs per GPU per step (BASELINE cfg2: 256)")
+    ap.add_argument("--points", type=int, default=2048)
+    ap.add_argument("--kernel", type=int, default=64, help="restarts per pair (houv.py:142 default)")
+    ap.add_argument("--iters", type=int, default=200, help="Adam iterations per stage (houv.py:142 default)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-chamfer-op", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(points, kernel, iters, inst_iters_per_pair):
+    """Time the oracle's predict_model (float64 expanded-form Chamfer + autograd + torch Adam = the reference's
+    PyTorch-CPU path) on 1 pair x 8 restarts... see `sample`; scale linearly in hypothesis-iterations (cost is
+    exactly linear in them) to the work the GPU run did per pair."""
+    from houv_amd import synthetic
+    from oracle import houv_ref_cpu as orc
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    src, tgt, _ = synthetic.make_pairs(1, points, seed=4242)
+    k_s, it_s = 26, 1                      # 26 = the fewest restarts reset_weight accepts (houv.py:47-51)
+    orc.predict_model(src, tgt, kernel=k_s, num_epochs=1)          # warm-up (allocator, threads)
+    t0 = time.time()
+    n_done = 0
+    while time.time() - t0 < 12.0:
+        orc.predict_model(src, tgt, kernel=k_s, num_epochs=it_s)
+        n_done += k_s * it_s
+    dt = time.time() - t0
+    per = dt / n_done
+    return {"value": 1.0 / (per * inst_iters_per_pair), "unit": "pairs/s", "cores": cores, "kind": "port",
+            "sample": f"{n_done} hypothesis-iterations of oracle.predict_model at {points}x{points} points "
+                      f"({dt:.1f} s, {per:.3f} s each), scaled linearly to the {inst_iters_per_pair:.0f} "
+                      "hypothesis-iterations per pair the GPU run executed",
+            "seconds_per_hypothesis_iteration": per}
+
+
+def chamfer_op_probe(dev, points):
+    from houv_amd import ops
+    B = 4096
+    a = torch.rand(B, points, 3, device=dev) - 0.5
+    b = torch.rand(B, points, 3, device=dev) - 0.5
+    d1 = torch.empty(B, points, device=dev); d2 = torch.empty_like(d1)
+    i1 = torch.empty(B, points, dtype=torch.int32, device=dev); i2 = torch.empty_like(i1)
+    ops.chamfer_forward(a, b, d1, d2, i1, i2)
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(5):
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        e0.record(); ops.chamfer_forward(a, b, d1, d2, i1, i2); e1.record(); torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1) * 1e-3)
+    t = float(np.mean(ts))
+    flops = 2.0 * B * points * points * FLOP_PER_EVAL
+    byts = B * (2 * points * 12 + 2 * points * 8)            # inputs 2*N*12 B + outputs 2*N*8 B
+    return {"kernel": "houv::chamfer_nn_kernel<4>", "batch": B, "points": points, "ms_per_launch": t * 1e3,
+            "tflops": flops / t / 1e12, "frac_fp32_peak": flops / t / 1e12 / FP32_PEAK_TFLOPS,
+            "algorithmic_GBps": byts / t / 1e9, "frac_hbm_peak": byts / t / 1e9 / HBM_PEAK_GBPS}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (there is no CPU fallback)"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    from houv_amd import distributed as hd
+    from houv_amd import solver, synthetic
+    from houv_amd.models.houv import HOUV
+
+    P = args.pairs
+    n_total = P * world
+    # synthetic MVP-shaped pairs, a different slice per rank and per step; resident in HBM before timing starts
+    n_batches = args.steps + args.warmup
+    batches = []
+    for b in range(n_batches):
+        s, t, pose = synthetic.make_pairs(P, args.points, seed=2021, first_id=(b * world + rank) * P)
+        batches.append((s.to(dev), t.to(dev), pose.to(dev)))
+    net = HOUV(P * args.kernel, 0).to(dev)
+    results = []
+
+    from houv_amd.models.houv import predict_model
+
+    def solve_on_device(s, t):
+        # solve_model (houv.py:142-206) without its final .cpu()/print: transforms stay in HBM for the all-gather
+        ans, _, _ = solver.best_of_k_with_retry(
+            lambda ss, tt, base: predict_model(net, ss, tt, kernel=args.kernel, num_epochs=args.iters, angle_base=base),
+            s, t)
+        return ans
+
+    def step(b):
+        s, t, _ = batches[b]
+        ans = solve_on_device(s, t)
+        full = hd.gather_transforms(ans, n_total) if world > 1 else ans      # ONE all-gather of [P,12] per rank
+        results.append((b, full))
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for w in range(args.warmup):
+        step(w)
+    results.clear()
+    solver.LAUNCH_LOG = []
+    sync()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(args.warmup + k)
+    sync()
+    dt = time.perf_counter() - t0
+    log, solver.LAUNCH_LOG = solver.LAUNCH_LOG, None
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    # ---- accuracy of what was just timed (sanity, rank-local batch of the last step) ----
+    from houv_amd.train_utils import rotation_error, translation_error
+    b_last, full = results[-1]
+    pose = batches[b_last][2]
+    mine = full[rank * P:(rank + 1) * P] if world > 1 else full
+    r_err = rotation_error(mine[:, :3, :3], pose[:, :3, :3])
+    t_err = translation_error(mine[:, :3, 3], pose[:, :3, 3])
+
+    # ---- dominant kernel: live HIP-event timing on the launch stream ----
+    k_ms = sum(e0.elapsed_time(e1) for e0, e1, *_ in log)
+    inst_iters = sum(n * it for _, _, n, it, *_ in log)
+    evals = sum(n * it * 8.0 * N * M for _, _, n, it, N, M, v in log)        # 4 metrics x 2 directions x N x M
+    flops = evals * FLOP_PER_EVAL
+    achieved = flops / (k_ms * 1e-3) / 1e12
+    roofline = {
+        "kernel": "houv::solve_kernel<512,4,4>", "bound": "valu-fp32",
+        "achieved": achieved, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP32_PEAK_TFLOPS,
+        "traffic": None,
+        "launches": len(log), "avg_launch_ms": k_ms / max(len(log), 1),
+        "us_per_hypothesis_iteration": k_ms * 1e3 / max(inst_iters, 1),
+        "kernel_time_share": k_ms * 1e-3 / dt,
+        "definition": "algorithmic flops = hypothesis-iterations x 8 sweeps x N*M x 8 flop (SURVEY.md 8d); the fused "
+                      "4-metric sweep executes 11 VALU instructions per point pair instead of 4x7, see DESIGN.md",
+        # physical view: VALU issue slots the sweeps need (11.4 lane-ops per 4-metric pair, 2 sweeps) over what the chip has
+        "valu_issue_frac_sweeps": (inst_iters * 2.0 * args.points * args.points * 11.4 / 64 * 2) /
+                                  (k_ms * 1e-3 * 2.4e9 * 1024),
+    }
+    out = {
+        "metric": "registration pairs/sec (2048-pt partial pairs)", "value": n_total * args.steps / dt,
+        "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"HOUV solve_model, {args.points}x{args.points}-pt pairs, batch {P}/GPU, "
+                               f"K={args.kernel} restarts x {args.iters} Adam iterations + retry stages "
+                               "(BASELINE configs[1])",
+                   "pairs_per_gpu": P, "points": args.points, "kernel": args.kernel, "iters": args.iters,
+                   "parallelism": f"dp{world} (pair shards, one RCCL all-gather of [P,12] per step)"},
+        "quality": {"mean_rot_err_deg": float(r_err.mean()), "median_rot_err_deg": float(r_err.median()),
+                    "mean_trans_err": float(t_err.mean()),
+                    "hypothesis_iterations_per_pair": inst_iters / (P * args.steps)},
+        "roofline": roofline,
+    }
+    if rank == 0 and world == 1:
+        if not args.no_chamfer_op:
+            out["chamfer_op"] = chamfer_op_probe(dev, args.points)
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.points, args.kernel, args.iters, inst_iters / (P * args.steps))
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

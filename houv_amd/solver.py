@@ -9,6 +9,10 @@ from . import ops
 RETRY_THRESHOLD = 0.030      # houv.py:156, train_utils.py:494 (strict >)
 ITERS_PER_LAUNCH = 50        # bound single-launch duration; state round-trips through HBM (192 B/hypothesis)
 
+# bench.py sets this to a list to collect (start_event, end_event, hypotheses, iterations, N, M, use_views) per
+# houv_solve_iterate launch: HIP events recorded on the stream the kernel is launched on.
+LAUNCH_LOG = None
+
 # the 26 non-zero {-1,0,1}^3 axes in the reference's loop order (houv.py:44-51)
 LATTICE_AXES = np.array([(x, y, z) for x in (-1, 0, 1) for y in (-1, 0, 1) for z in (-1, 0, 1)
                          if (x, y, z) != (0, 0, 0)], dtype=np.float64)
@@ -52,6 +56,11 @@ def run_stage(src, tgt, params, K, n_iters, *, angle_base, trans_mode, use_views
     src = src.contiguous().float()
     tgt = tgt.contiguous().float()
     P, N, _ = src.shape
+    if use_views and tgt.shape[1] != N:
+        # loss_view multiplies the target by a mask shaped like the moved cloud (model_utils_completion.py:158-163):
+        # the reference raises on N != M whenever the view terms are on.
+        raise RuntimeError(f"The size of tensor a ({tgt.shape[1]}) must match the size of tensor b ({N}) at "
+                           "non-singleton dimension 1")
     dev = src.device
     n = P * K
     state = torch.zeros((n, 24), dtype=torch.float64, device=dev)
@@ -66,10 +75,17 @@ def run_stage(src, tgt, params, K, n_iters, *, angle_base, trans_mode, use_views
     while done < n_iters:
         it = min(step, n_iters - done)
         last = done + it == n_iters
+        if LAUNCH_LOG is not None:
+            ev0 = torch.cuda.Event(enable_timing=True)
+            ev1 = torch.cuda.Event(enable_timing=True)
+            ev0.record(torch.cuda.current_stream(dev))
         out = ops.solve_iterate(src, tgt, state, K, steps_done=done, n_iters=it, angle_base=angle_base,
                                 trans_mode=trans_mode, use_views=use_views, f64_params=f64_params, k_full=k_full,
                                 k_view=k_view, lr=lr, loss_scale=1.0 / n, want_grad=want_grad and last,
                                 want_cd=want_cd and last)
+        if LAUNCH_LOG is not None:
+            ev1.record(torch.cuda.current_stream(dev))
+            LAUNCH_LOG.append((ev0, ev1, n, it, N, tgt.shape[1], bool(use_views)))
         done += it
     return out, state
 

@@ -75,6 +75,7 @@ def test_metrics_golden(golden, dev):
     from houv_amd.train_utils import rmse_loss, rotation_error, translation_error
     g = golden("g8_metrics.npz")
     Ta, Tb = T(g["Ta"]).to(dev), T(g["Tb"]).to(dev)
-    np.testing.assert_allclose(rotation_error(Ta[:, :3, :3], Tb[:, :3, :3]).cpu().numpy(), g["rot_err"], atol=2e-3)
+    # acos is ill-conditioned at 0 deg: a 1-ulp change of the fp32 trace moves identical rotations by 0.03 deg
+    np.testing.assert_allclose(rotation_error(Ta[:, :3, :3], Tb[:, :3, :3]).cpu().numpy(), g["rot_err"], atol=5e-2)
     np.testing.assert_allclose(translation_error(Ta[:, :3, 3], Tb[:, :3, 3]).cpu().numpy(), g["trans_err"], atol=1e-6)
     np.testing.assert_allclose(rmse_loss(T(g["pts"]).to(dev), Ta, Tb).cpu().numpy(), g["rmse"], atol=1e-6)

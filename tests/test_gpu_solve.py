@@ -34,7 +34,7 @@ def _oracle_terms(src, tgt, params, base, mode="houv"):
                 R=R.detach().numpy(), T=Tt.detach().numpy()[:, 0])
 
 
-@pytest.mark.parametrize("N,M,base,mode", [(128, 128, 0, "houv"), (200, 200, 2, "houv"), (96, 160, 1, "houv"),
+@pytest.mark.parametrize("N,M,base,mode", [(128, 128, 0, "houv"), (200, 200, 2, "houv"), (96, 160, 1, "solve"),
                                            (300, 300, 3, "solve"), (600, 600, 0, "houv"), (1100, 1100, 1, "houv")])
 def test_single_forward_backward_vs_oracle(dev, N, M, base, mode):
     """Per-op rung: the 8 Chamfer terms (1e-5, north_star's Chamfer bar), loss, min_1, R/T and the parameter
@@ -60,7 +60,13 @@ def test_single_forward_backward_vs_oracle(dev, N, M, base, mode):
     np.testing.assert_allclose(out["T"].cpu().numpy(), want["T"], atol=1e-6)
     g = out["grad"].cpu().numpy()
     scale = np.abs(want["grads"]).max(axis=1, keepdims=True)
-    np.testing.assert_allclose(g / scale, want["grads"] / scale, rtol=0, atol=2e-4)
+    err = (np.abs(g - want["grads"]) / scale).max(axis=1)
+    # The oracle's float64 search is exact; the fp32 direct-difference search (ours, and the reference's CUDA kernel)
+    # may take the other point of a pair tied to within fp32 rounding (relative margin ~1e-7).  One such flip moves
+    # a hypothesis' gradient by one point's share, <= ~2/N, and leaves the loss unchanged: allow it on at most one
+    # hypothesis of the 30; everything else must agree to 2e-4 of the gradient's largest component.
+    assert (err > 2e-4).sum() <= 1, err
+    assert err.max() < 3.0 / min(N, M), err
 
 
 def test_golden_single_step_and_trajectory(golden, dev):
@@ -154,8 +160,11 @@ def test_topk_size_out_of_range_is_an_error(dev):
     """topk(k) with k > number of points raises in the reference (model_utils_completion.py:91): M < N with views."""
     from houv_amd import _lib, solver, synthetic
     src, tgt, _ = synthetic.make_pairs(2, 64, seed=1)
-    with pytest.raises(_lib.HouvHipError):
+    with pytest.raises(RuntimeError):      # views on and N != M: the reference's mask broadcast fails (loss_view)
         solver.run_stage(src.to(dev), tgt[:, :40].contiguous().to(dev), solver.houv_init_params(26 * 2), 26, 1,
                          angle_base=0, trans_mode=0, use_views=True, f64_params=False, lr=0.01)
+    with pytest.raises(_lib.HouvHipError):  # views off, k = N/2 = 32 > M = 20: topk out of range
+        solver.run_stage(src.to(dev), tgt[:, :20].contiguous().to(dev), solver.houv_init_params(26 * 2), 26, 1,
+                         angle_base=0, trans_mode=1, use_views=False, f64_params=True, lr=0.1)
     with pytest.raises(IndexError):
         solver.houv_init_params(25)                                   # houv.py:47-51 has no bounds check
