@@ -22,15 +22,17 @@ def _oracle_terms(src, tgt, params, base, mode="houv"):
     tv = [T(params[:, 0:3].astype(np.float32), requires_grad=True), T(params[:, 3:4].astype(np.float32), requires_grad=True),
           T(params[:, 4:7].astype(np.float32), requires_grad=True), T(params[:, 7:8].astype(np.float32), requires_grad=True)]
     moved, R, Tt = orc.houv_forward(src, *tv, base, mode)
-    cds = [orc.calc_cd_percent(moved, tgt, percent=0.5)] + [orc.loss_view(moved, tgt, dim=d) for d in range(3)]
+    cds = [orc.calc_cd_percent(moved, tgt, percent=0.5)]
+    if mode == "houv":
+        cds += [orc.loss_view(moved, tgt, dim=d) for d in range(3)]
     if mode == "houv":
         loss, min1 = orc.predict_loss(moved, tgt)
     else:
         min1 = torch.minimum(*cds[0]); loss = min1 * 6
     loss.mean().backward()
-    cd = np.stack([np.stack([c[0].detach().numpy(), c[1].detach().numpy()], 1) for c in cds], 1)   # [n,4,2]
+    cd = np.stack([np.stack([c[0].detach().numpy(), c[1].detach().numpy()], 1) for c in cds], 1)   # [n,4|1,2]
     grads = np.concatenate([t.grad.numpy() for t in tv], 1)
-    return dict(cd=cd.reshape(len(params), 8), loss=loss.detach().numpy(), min1=min1.detach().numpy(), grads=grads,
+    return dict(cd=cd.reshape(len(params), -1), loss=loss.detach().numpy(), min1=min1.detach().numpy(), grads=grads,
                 R=R.detach().numpy(), T=Tt.detach().numpy()[:, 0])
 
 
