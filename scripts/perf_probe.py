@@ -30,7 +30,7 @@ src, tgt, _ = synthetic.make_pairs(P, N, seed=1)
 src, tgt = src.to(dev), tgt.to(dev)
 p0 = solver.houv_init_params(P * K)
 for views in (True, False):
-    for iters in (4,):
+    for iters in (int(os.environ.get("ITERS", 4)),):
         def run():
             solver.run_stage(src, tgt, p0, K, iters, angle_base=0, trans_mode=0, use_views=views, f64_params=False, lr=0.01)
         mn, md = timed(run, n=2)

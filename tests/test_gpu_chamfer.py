@@ -68,6 +68,22 @@ def test_ragged_shapes_vs_oracle(dev, B, N, M):
     np.testing.assert_allclose(d2.cpu().numpy(), o2.numpy(), rtol=1e-4, atol=1e-7)
 
 
+@pytest.mark.parametrize("B,N,M", [(4, 2048, 2048), (3, 777, 1500), (2, 2500, 300), (16, 512, 512)])
+def test_bit_exact_vs_c_oracle(dev, B, N, M):
+    """Integer/index bar: against oracle/chamfer_ref.c (fp32 direct differences, the CUDA kernel's arithmetic with the
+    same fma contraction) distances must be BIT-identical and indices exactly equal, ties included."""
+    from oracle import c_oracle
+    gen = torch.Generator().manual_seed(N * 7 + M)
+    a = torch.rand(B, N, 3, generator=gen) - 0.5
+    b = torch.rand(B, M, 3, generator=gen) - 0.5
+    b[:, M // 2] = b[:, 0]                       # exact duplicates -> genuine ties
+    d1, d2, i1, i2 = _cd(a, b, dev)
+    o1, o2, j1, j2 = c_oracle.chamfer_forward(a.numpy(), b.numpy())
+    assert np.array_equal(d1.cpu().numpy().view(np.uint32), o1.view(np.uint32))
+    assert np.array_equal(d2.cpu().numpy().view(np.uint32), o2.view(np.uint32))
+    assert np.array_equal(i1.cpu().numpy(), j1) and np.array_equal(i2.cpu().numpy(), j2)
+
+
 def test_ties_pick_lowest_index(dev):
     """Duplicated reference points: the lowest index must win, across sub-tile (32) and LDS-tile (2048) borders."""
     gen = torch.Generator().manual_seed(5)

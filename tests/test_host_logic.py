@@ -1,0 +1,122 @@
+"""CPU tests of the host-side mirrors that need no GPU: config surface, import aliasing, shard files, parameter
+initialisation quirks, synthetic data generator."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+
+def test_config_accepts_reference_yaml_surface(tmp_path):
+    from houv_amd.config import load_config
+    p = tmp_path / "houv.yaml"
+    # the key set of registration/cfgs/houv.yaml (values abridged)
+    p.write_text("batch_size: 100\nworkers: 0\nnepoch: 100\nmodel_name: houv\nload_model: null\nwork_dir: log/\n"
+                 "flag: debug\nloss: cd\nmanual_seed: 2021\nnum_points: 2048\nmax_angle: 180\nmax_trans: 0.5\n"
+                 "benchmark: mvp\nkernel: 32\nlr: 0.01\nbetas: 0.9, 0.999\neval_emd: False\nl: 0\nr: 4\ncombine: False\n")
+    a = load_config(str(p))
+    assert a.batch_size == 100 and a["kernel"] == 32 and a.load_model is None and a.combine is False
+    assert a.betas == "0.9, 0.999" and "manual_seed" in str(a)
+    a.l = 7
+    assert a["l"] == 7
+    with pytest.raises(AttributeError):
+        a.nope
+
+
+def test_compat_aliases_resolve_reference_imports():
+    from houv_amd import compat
+    saved = {k: sys.modules.get(k) for k in ("metrics", "models", "models.houv", "train_utils", "model_utils",
+                                             "model_utils_completion")}
+    for k in saved:
+        sys.modules.pop(k, None)
+    try:
+        compat.install()
+        from metrics import cd                                                    # noqa: F401
+        from models.houv import HOUV, Predict_loss, predict_model, solve_model    # noqa: F401
+        from train_utils import (AverageValueMeter, rmse_loss, rotation_error, solve,   # noqa: F401
+                                 translation_error)
+        from model_utils import SVDHead                                            # noqa: F401
+        import houv_amd.models.houv as mine
+        assert predict_model is mine.predict_model
+    finally:
+        compat.uninstall()
+        for k, v in saved.items():
+            if v is not None:
+                sys.modules[k] = v
+
+
+def test_signatures_match_reference():
+    """Argument names and defaults of the drop-in entry points (houv.py:14,40,94,106,142,209; train_utils.py:359,467)."""
+    import inspect
+    from houv_amd.models import houv
+    from houv_amd import train_utils, model_utils
+    sig = lambda f: str(inspect.signature(f))
+    assert sig(houv.predict_model) == ("(net, src, src_rotated, pose=None, src_ori=None, tgt_ori=None, angle_t=None, "
+                                       "label=None, kernel=64, num_epochs=500, angle_base=0, device='cuda', seed=2021)")
+    assert sig(houv.solve_model) == ("(net, src, src_rotated, pose=None, src_ori=None, tgt_ori=None, angle_t=None, "
+                                     "label=None, kernel=64, num_epochs=200, prefix='train')")
+    assert sig(houv.Predict_loss) == "(src, src_rotated, alpha=0.5)"
+    assert sig(houv.HOUV.reset_weight) == "(self, batch_size, angle_base, seed=2021)"
+    assert sig(houv.HOUV.__init__) == "(self, batch_size, angle_base)"
+    assert sig(train_utils.solve).startswith("(src, src_rotated, pose=None, src_ori=None, tgt_ori=None, angle_t=None, "
+                                             "label=None, kernel=64, num_epochs=500, prefix='train'")
+    assert sig(train_utils.getPredict_angle) == ("(src, src_rotated, pose=None, src_ori=None, tgt_ori=None, "
+                                                 "angle_t=None, label=None, kernel=64, num_epochs=1000, angle_base=0)")
+    assert sig(model_utils.SVDHead.forward) == "(self, src, src_corr, weights=None)"
+
+
+def test_param_init_matches_golden_and_quirks(golden):
+    from houv_amd import solver
+    g = golden("g3_g4_params_forward.npz")
+    p = solver.houv_init_params(32, 2021).astype(np.float32)
+    want = np.concatenate([g["V"], g["angle"], g["tran_c"], g["tran_s"]], 1)
+    np.testing.assert_array_equal(p, want)
+    with pytest.raises(IndexError):
+        solver.houv_init_params(25)
+    # the `solve` twin draws from the global RNG in the reference's order (and burns the unused angle_XYZ draw)
+    np.random.seed(3)
+    a = solver.solve_twin_init_params(5)
+    np.random.seed(3)
+    V = np.random.randn(5, 3); an = np.random.randn(5, 1); c = np.random.randn(5, 3); s = np.random.randn(5, 1)
+    np.random.randn(5, 3)
+    nxt = np.random.randn()
+    np.testing.assert_array_equal(a, np.concatenate([V, an, c, s], 1))
+    np.random.seed(3); solver.solve_twin_init_params(5)
+    assert np.random.randn() == nxt
+
+
+def test_houv_module_parameters_mirror_reference():
+    from houv_amd.models.houv import HOUV
+    net = HOUV(40, 0)
+    names = [n for n, _ in net.named_parameters()]
+    assert names == ["V_c", "angle_c", "tran_c", "tran_s_cpu"]          # quirk A.5(5): tran_s only after reset_weight
+    net.reset_weight(40, 1)
+    assert "tran_s" in dict(net.named_parameters()) and net.angle_base == 1
+    assert tuple(net.packed_params().shape) == (40, 8)
+    small = HOUV(5, 0)                                                  # __init__ (unlike reset_weight) bounds the lattice fill
+    assert tuple(small.V_c.shape) == (5, 3)
+
+
+def test_shard_files_and_combine(tmp_path):
+    from houv_amd import io as hio
+    rng = np.random.default_rng(0)
+    parts = [rng.standard_normal((5, 4, 4)).astype(np.float32) for _ in range(4)]
+    for i, p in enumerate(parts):
+        hio.save_shard(str(tmp_path), 5 * i, 5 * i + 5, p)
+    res = hio.combine_shards(str(tmp_path), step=5, num=4)
+    np.testing.assert_array_equal(res, np.concatenate(parts, 0))
+    out = hio.save_results(str(tmp_path), res)
+    assert os.path.exists(out)
+    np.testing.assert_array_equal(np.load(os.path.join(str(tmp_path), "results.npy")), res)
+
+
+def test_synthetic_pairs_are_mvp_shaped():
+    from houv_amd import synthetic
+    s, t, T = synthetic.make_pairs(5, 256, seed=1)
+    assert s.shape == (5, 256, 3) and t.shape == (5, 256, 3) and T.shape == (5, 4, 4) and s.dtype == torch.float32
+    R = T[:, :3, :3]
+    np.testing.assert_allclose((R @ R.transpose(1, 2)).numpy(), np.broadcast_to(np.eye(3), (5, 3, 3)), atol=1e-5)
+    assert float(T[:, :3, 3].norm(dim=1).max()) <= 0.25 + 1e-6          # random_translation(0.25)
+    s2, _, _ = synthetic.make_pairs(5, 256, seed=1)
+    assert torch.equal(s, s2)                                            # deterministic per (seed, pair id)

@@ -118,3 +118,21 @@ def test_g8_metrics(golden):
     np.testing.assert_array_equal(orc.rotation_error(Ta[:, :3, :3], Tb[:, :3, :3]).numpy(), g["rot_err"])
     np.testing.assert_array_equal(orc.translation_error(Ta[:, :3, 3], Tb[:, :3, 3]).numpy(), g["trans_err"])
     np.testing.assert_array_equal(orc.rmse_loss(T(g["pts"]), Ta, Tb).numpy(), g["rmse"])
+
+
+def test_c_oracle_pinned_to_golden(golden):
+    """oracle/chamfer_ref.c (fp32 direct-difference restatement of chamfer3D.cu) against the reference's outputs:
+    indices exactly equal (unit_test.py:29-33), distances = fp32 rounding noise of the float64 values."""
+    from oracle import c_oracle
+    g = golden("g1_chamfer.npz")
+    d1, d2, i1, i2 = c_oracle.chamfer_forward(g["p1"], g["p2"])
+    assert np.array_equal(i1, g["idx1"]) and np.array_equal(i2, g["idx2"])
+    np.testing.assert_allclose(d1, g["dist1"], rtol=2e-5, atol=1e-7)
+    np.testing.assert_allclose(d2, g["dist2"], rtol=2e-5, atol=1e-7)
+    assert ((d1 - g["dist1"]) ** 2).mean() + ((d2 - g["dist2"]) ** 2).mean() < 1e-8      # unit_test.py:23-27
+    b1, b2, j1, j2 = c_oracle.chamfer_forward(g["big_a"], g["big_b"])
+    assert (j1 != g["big_idx1"]).sum() + (j2 != g["big_idx2"]).sum() <= 2                 # fp32 near-ties only
+    np.testing.assert_allclose(b1, g["big_dist1"], rtol=1e-4, atol=1e-7)
+    gx1, gx2 = c_oracle.chamfer_backward(g["q1"], g["q2"], g["w1"], g["w2"], g["j1"], g["j2"])
+    np.testing.assert_allclose(gx1, g["grad_q1"], rtol=1e-4, atol=2e-6)
+    np.testing.assert_allclose(gx2, g["grad_q2"], rtol=1e-4, atol=2e-6)
