@@ -143,17 +143,19 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    solver.LAUNCH_LOG = []
     for w in range(args.warmup):
         step(w)
     results.clear()
-    solver.LAUNCH_LOG = []
+    n_warm_launches = len(solver.LAUNCH_LOG)
     sync()
     t0 = time.perf_counter()
     for k in range(args.steps):
         step(args.warmup + k)
     sync()
     dt = time.perf_counter() - t0
-    log, solver.LAUNCH_LOG = solver.LAUNCH_LOG, None
+    log_all, solver.LAUNCH_LOG = solver.LAUNCH_LOG, None
+    log = log_all[n_warm_launches:]
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -178,6 +180,9 @@ def main():
         "achieved": achieved, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP32_PEAK_TFLOPS,
         "traffic": None,
         "launches": len(log), "avg_launch_ms": k_ms / max(len(log), 1),
+        # all launches of the process (warm-up included) = what `rocprofv3 --kernel-trace --stats` averages over
+        "launches_incl_warmup": len(log_all),
+        "avg_launch_ms_incl_warmup": sum(e0.elapsed_time(e1) for e0, e1, *_ in log_all) / max(len(log_all), 1),
         "us_per_hypothesis_iteration": k_ms * 1e3 / max(inst_iters, 1),
         "kernel_time_share": k_ms * 1e-3 / dt,
         "definition": "algorithmic flops = hypothesis-iterations x 8 sweeps x N*M x 8 flop (SURVEY.md 8d); the fused "
