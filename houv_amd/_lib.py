@@ -9,7 +9,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libhouv_hip.so")
+# HOUV_HIP_LIB lets the diagnostic scripts load the stamped build variant; the default is the product library
+LIB_PATH = os.environ.get("HOUV_HIP_LIB") or os.path.join(_HERE, "lib", "libhouv_hip.so")
 ABI_VERSION = 1
 
 _c_f = ctypes.c_void_p     # device pointers travel as plain addresses
@@ -26,6 +27,7 @@ _SIGNATURES = {
     "houv_solve_iterate": (ctypes.c_int, [_c_f, _c_f, _int, _int, _int, _int, _c_f, _int, _int, _int, _int, _int, _int,
                                           _int, _int, _dbl, _dbl, _dbl, _dbl, _flt, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f,
                                           _c_f]),
+    "houv_icp_refine": (ctypes.c_int, [_c_f, _c_f, _int, _int, _int, _c_f, _flt, _int, _flt, _flt, _c_f, _c_f, _c_f, _c_f, _c_f]),
     "houv_pose_forward": (ctypes.c_int, [_c_f, _int, _int, _int, _c_f, _int, _c_f, _c_f, _c_f, _c_f]),
 }
 

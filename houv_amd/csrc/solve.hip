@@ -22,6 +22,7 @@
 //   * the un-moved source point needed for sum G p^T in the target->moved direction is R^T(p' - T).
 #include "../../include/houv_hip.h"
 #include "houv_common.h"
+#include "houv_sweep.h"
 
 namespace houv {
 namespace {
@@ -42,8 +43,28 @@ struct SolveArgs {
   float* out_cd;
 };
 
+#ifdef HOUV_STAMPS
+// Diagnostic build only (scripts/stamps.sh): per-phase wave-cycle totals, never read by the kernel itself.
+__device__ unsigned long long g_stamp[16];
+#define HOUV_STAMP(i)                                                        \
+  do {                                                                       \
+    const unsigned long long now_ = __builtin_readcyclecounter();           \
+    if ((threadIdx.x & 63) == 0) atomicAdd(&g_stamp[i], now_ - t_stamp_);   \
+    t_stamp_ = now_;                                                         \
+  } while (0)
+#define HOUV_STAMP_PARAM , unsigned long long& t_stamp_
+#define HOUV_STAMP_ARG , t_stamp_
+#else
+#define HOUV_STAMP(i) do {} while (0)
+#define HOUV_STAMP_PARAM
+#define HOUV_STAMP_ARG
+#endif
+
+#ifndef HOUV_RESCAN_BATCH
+#define HOUV_RESCAN_BATCH 4
+#endif
+constexpr int kRescanBatch = HOUV_RESCAN_BATCH;
 constexpr int kAccN = 13;      // sum sqrt(d), G[3], (G p^T)[9]
-constexpr int kAccStride = 16;
 
 struct Smem {
   float4* tgt;     // [Mpad]
@@ -76,84 +97,6 @@ __device__ inline Smem carve(unsigned char* base, int N, int M, int block) {
   s.hist = reinterpret_cast<unsigned*>(s.red + nw * kAccStride);
   s.ctl = reinterpret_cast<int*>(s.hist + 256);
   return s;
-}
-
-// ------------------------------------------------------------------------------------------------
-// The brute-force sweep: for each of this lane's Q queries, min over all references of the NMET
-// squared distances, plus the id of the 32-reference sub-tile that produced each minimum.
-// ------------------------------------------------------------------------------------------------
-template <int Q, int NMET>
-__device__ __forceinline__ void sweep(const float4* __restrict__ refs, int ntile, const float (&qx)[Q],
-                                      const float (&qy)[Q], const float (&qz)[Q], float (&best)[Q][NMET],
-                                      int (&btile)[Q][NMET]) {
-#pragma unroll
-  for (int k = 0; k < Q; ++k)
-#pragma unroll
-    for (int m = 0; m < NMET; ++m) {
-      best[k][m] = INFINITY;
-      btile[k][m] = 0;
-    }
-  for (int t = 0; t < ntile; ++t) {
-    float tm[Q][NMET];
-#pragma unroll
-    for (int k = 0; k < Q; ++k)
-#pragma unroll
-      for (int m = 0; m < NMET; ++m) tm[k][m] = INFINITY;
-    const float4* rp = refs + t * kSub;
-#pragma unroll 4
-    for (int j = 0; j < kSub; j += 2) {
-      const float4 a = rp[j], c = rp[j + 1];
-      // keep .w "used" so the loads stay ds_read_b128 (4 LDS cycles) instead of ds_read_b96 (8)
-      asm volatile("" ::"v"(a.w), "v"(c.w));
-#pragma unroll
-      for (int k = 0; k < Q; ++k) {
-        const float ax = a.x - qx[k], ay = a.y - qy[k], az = a.z - qz[k];
-        const float cx = c.x - qx[k], cy = c.y - qy[k], cz = c.z - qz[k];
-        if constexpr (NMET == 4) {
-          const float axx = ax * ax, ayy = ay * ay, cxx = cx * cx, cyy = cy * cy;
-          const float a3 = __builtin_fmaf(ay, ay, axx), c3 = __builtin_fmaf(cy, cy, cxx);   // z dropped
-          const float a1 = __builtin_fmaf(az, az, ayy), c1 = __builtin_fmaf(cz, cz, cyy);   // x dropped
-          const float a2 = __builtin_fmaf(az, az, axx), c2 = __builtin_fmaf(cz, cz, cxx);   // y dropped
-          const float a0 = __builtin_fmaf(az, az, a3), c0 = __builtin_fmaf(cz, cz, c3);     // full
-          tm[k][0] = min3f(tm[k][0], a0, c0);
-          tm[k][1] = min3f(tm[k][1], a1, c1);
-          tm[k][2] = min3f(tm[k][2], a2, c2);
-          tm[k][3] = min3f(tm[k][3], a3, c3);
-        } else {
-          tm[k][0] = min3f(tm[k][0], metric_sqdist<0>(ax, ay, az), metric_sqdist<0>(cx, cy, cz));
-        }
-      }
-    }
-#pragma unroll
-    for (int k = 0; k < Q; ++k)
-#pragma unroll
-      for (int m = 0; m < NMET; ++m) {
-        const bool lt = tm[k][m] < best[k][m];   // strict: earlier sub-tile keeps ties (lowest index wins)
-        best[k][m] = lt ? tm[k][m] : best[k][m];
-        btile[k][m] = lt ? t : btile[k][m];
-      }
-  }
-}
-
-// Sum NV per-thread values over the workgroup into out[0..NV) (LDS).
-template <int BLOCK, int NV>
-__device__ __forceinline__ void block_sum(float (&v)[NV], float* red, float* out) {
-  constexpr int NW = BLOCK / 64;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-  for (int i = 0; i < NV; ++i) v[i] = wave_sum(v[i]);
-  __syncthreads();
-  if (lane == 0) {
-#pragma unroll
-    for (int i = 0; i < NV; ++i) red[wave * kAccStride + i] = v[i];
-  }
-  __syncthreads();
-  if (threadIdx.x < NV) {
-    float a = 0.f;
-#pragma unroll
-    for (int w = 0; w < NW; ++w) a += red[w * kAccStride + threadIdx.x];
-    out[threadIdx.x] = a;
-  }
 }
 
 // Exact selection of the `ksel` smallest of the BLOCK*Q keys (fp32 bit patterns of non-negative
@@ -230,34 +173,24 @@ template <int BLOCK, int Q, int MET, int DIR>
 __device__ __forceinline__ void epilogue_metric(const Smem& sm, const float4* __restrict__ refs, const float (&qx)[Q],
                                                 const float (&qy)[Q], const float (&qz)[Q], const float (&bestm)[Q],
                                                 const int (&btilem)[Q], int count, int ksel, const float (&px)[Q],
-                                                const float (&py)[Q], const float (&pz)[Q], float* acc_out) {
+                                                const float (&py)[Q], const float (&pz)[Q], float* acc_out HOUV_STAMP_PARAM) {
   const int tid = threadIdx.x;
+  const int rot = tid & (kSub - 1);
   float nx[Q], ny[Q], nz[Q];
   unsigned key[Q];
   bool sel[Q];
 #pragma unroll
   for (int k = 0; k < Q; ++k) {
-    const float4* rp = refs + btilem[k] * kSub;
     const float bd = bestm[k];
-    // Every lane scans ITS sub-tile; sub-tile bases are multiples of 32 rows (512 B), so scanning them all in the
-    // same order would put all lanes of an LDS lane-group on the same banks (measured: 7x conflict slow-down).
-    // Rotating the scan order by the lane id makes the 16 lanes of a ds_read_b128 group hit 16 different bank quads.
-    int jb = kSub;
-#pragma unroll 4
-    for (int j = 0; j < kSub; ++j) {
-      const int jr = (j + tid) & (kSub - 1);
-      const float4 r = rp[jr];
-      asm volatile("" ::"v"(r.w));   // keep it a ds_read_b128
-      const float d = metric_sqdist<MET>(r.x - qx[k], r.y - qy[k], r.z - qz[k]);
-      jb = min(jb, (d == bd) ? jr : kSub);   // the lowest matching index wins, whatever the scan order
-    }
-    const float4 nn = rp[jb & (kSub - 1)];
+    const float4 nn = recover_nn<MET, kRescanBatch>(refs + btilem[k] * kSub, qx[k], qy[k], qz[k], bd, rot);
     nx[k] = nn.x; ny[k] = nn.y; nz[k] = nn.z;
     const bool valid = (k * BLOCK + tid) < count;
     key[k] = valid ? __float_as_uint(bd) : 0xFFFFFFFFu;
     sel[k] = valid;
   }
+  HOUV_STAMP(8);
   if (ksel < count) select_smallest<BLOCK, Q>(key, ksel, sm.hist, sm.ctl, sel);
+  HOUV_STAMP(9);
 
   float acc[kAccN];
 #pragma unroll
@@ -296,14 +229,16 @@ __device__ __forceinline__ void epilogue_metric(const Smem& sm, const float4* __
       acc[10] += cz * sx; acc[11] += cz * sy; acc[12] += cz * sz;
     }
   }
+  HOUV_STAMP(10);
   block_sum<BLOCK, kAccN>(acc, sm.red, acc_out);
+  HOUV_STAMP(11);
 }
 
 template <int BLOCK, int Q, int NMET, int DIR>
 __device__ __forceinline__ void epilogue(const Smem& sm, const float4* __restrict__ refs, const float (&qx)[Q],
                                          const float (&qy)[Q], const float (&qz)[Q], const float (&best)[Q][NMET],
                                          const int (&btile)[Q][NMET], int count, int k_full, int k_view,
-                                         const float (&px)[Q], const float (&py)[Q], const float (&pz)[Q]) {
+                                         const float (&px)[Q], const float (&py)[Q], const float (&pz)[Q] HOUV_STAMP_PARAM) {
   float bm[Q];
   int bt[Q];
 #define HOUV_EPI(MET)                                                                                              \
@@ -313,7 +248,7 @@ __device__ __forceinline__ void epilogue(const Smem& sm, const float4* __restric
       bt[k] = btile[k][MET];                                                                                       \
     }                                                                                                              \
     epilogue_metric<BLOCK, Q, MET, DIR>(sm, refs, qx, qy, qz, bm, bt, count, (MET == 0) ? k_full : k_view, px, py, \
-                                        pz, sm.acc + (MET * 2 + DIR) * kAccStride);                                \
+                                        pz, sm.acc + (MET * 2 + DIR) * kAccStride HOUV_STAMP_ARG);                 \
   }
   HOUV_EPI(0)
   if constexpr (NMET == 4) {
@@ -358,6 +293,9 @@ __global__ __launch_bounds__(BLOCK, 4) void solve_kernel(SolveArgs a) {
   }
   __syncthreads();
 
+#ifdef HOUV_STAMPS
+  unsigned long long t_stamp_ = __builtin_readcyclecounter();
+#endif
 #pragma unroll 1
   for (int it = 0; it < a.n_iters; ++it) {
     float best[Q][NMET];
@@ -384,9 +322,12 @@ __global__ __launch_bounds__(BLOCK, 4) void solve_kernel(SolveArgs a) {
         if (ok) sm.mov[i] = make_float4(mx[k], my[k], mz[k], 0.f);
       }
       __syncthreads();
+      HOUV_STAMP(0);
       // ---- sweep A: moved -> target ----
       sweep<Q, NMET>(sm.tgt, mpad / kSub, mx, my, mz, best, btile);
-      epilogue<BLOCK, Q, NMET, 1>(sm, sm.tgt, mx, my, mz, best, btile, N, a.k_full, a.k_view, sx, sy, sz);
+      HOUV_STAMP(1);
+      epilogue<BLOCK, Q, NMET, 1>(sm, sm.tgt, mx, my, mz, best, btile, N, a.k_full, a.k_view, sx, sy, sz HOUV_STAMP_ARG);
+      HOUV_STAMP(2);
     }
     {
       // ---- sweep B: target -> moved ----
@@ -398,9 +339,12 @@ __global__ __launch_bounds__(BLOCK, 4) void solve_kernel(SolveArgs a) {
         tx[k] = v.x; ty[k] = v.y; tz[k] = v.z;
       }
       sweep<Q, NMET>(sm.mov, npad / kSub, tx, ty, tz, best, btile);
-      epilogue<BLOCK, Q, NMET, 0>(sm, sm.mov, tx, ty, tz, best, btile, M, a.k_full, a.k_view, tx, ty, tz);
+      HOUV_STAMP(3);
+      epilogue<BLOCK, Q, NMET, 0>(sm, sm.mov, tx, ty, tz, best, btile, M, a.k_full, a.k_view, tx, ty, tz HOUV_STAMP_ARG);
+      HOUV_STAMP(4);
     }
     __syncthreads();
+    HOUV_STAMP(5);
 
     // ---- per-hypothesis scalar tail: loss, closed-form gradient, Adam, next pose ----
     if (tid == 0) {
@@ -474,6 +418,7 @@ __global__ __launch_bounds__(BLOCK, 4) void solve_kernel(SolveArgs a) {
       for (int k = 0; k < 3; ++k) sm.pose[9 + k] = f.T[k];
     }
     __syncthreads();
+    HOUV_STAMP(6);
   }
   if (tid < 24) a.state[(size_t)inst * 24 + tid] = sm.state[tid];
 }
@@ -497,6 +442,17 @@ int launch(const SolveArgs& a, int use_views, hipStream_t s) {
 
 }  // namespace
 }  // namespace houv
+
+#ifdef HOUV_STAMPS
+extern "C" int houv_debug_read_stamps(unsigned long long* host_out, int reset) {
+  if (hipMemcpyFromSymbol(host_out, HIP_SYMBOL(houv::g_stamp), sizeof(unsigned long long) * 16) != hipSuccess) return 0;
+  if (reset) {
+    unsigned long long z[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(houv::g_stamp), z, sizeof(z)) != hipSuccess) return 0;
+  }
+  return 1;
+}
+#endif
 
 extern "C" int houv_solve_iterate(const float* src, const float* tgt, int P, int N, int M, int K, double* state,
                                   int steps_done, int n_iters, int angle_base, int trans_mode, int use_views,

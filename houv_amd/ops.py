@@ -124,6 +124,34 @@ def solve_iterate(src, tgt, state, K, *, steps_done, n_iters, angle_base, trans_
     return out
 
 
+def icp_refine(src, tgt, init=None, max_correspondence_distance=0.02, max_iteration=500, relative_fitness=1e-6,
+               relative_rmse=1e-6):
+    """Batched point-to-point ICP (houv_icp_refine; Open3D registration_icp semantics, train_ICP.py:148-151).
+    src[P,N,3], tgt[P,M,3], init[P,4,4]|None -> dict(T[P,4,4], fitness[P], inlier_rmse[P], iterations[P])."""
+    _lib.require_gpu(src, tgt, init)
+    _want(src, _F32, "src"); _want(tgt, _F32, "tgt")
+    P, N, _ = src.shape
+    M = tgt.shape[1]
+    if tgt.shape[0] != P or src.shape[2] != 3 or tgt.shape[2] != 3:
+        raise _lib.HouvHipError("icp_refine: expected src[P,N,3], tgt[P,M,3]")
+    if init is not None:
+        _want(init, _F32, "init")
+        if tuple(init.shape) != (P, 4, 4):
+            raise _lib.HouvHipError("icp_refine: init must be [P,4,4]")
+    dev = src.device
+    T = torch.empty((P, 4, 4), dtype=_F32, device=dev)
+    fit = torch.empty(P, dtype=_F32, device=dev)
+    rmse = torch.empty(P, dtype=_F32, device=dev)
+    iters = torch.empty(P, dtype=_I32, device=dev)
+    with torch.cuda.device(dev):
+        ok = _lib.load().houv_icp_refine(_lib.ptr(src), _lib.ptr(tgt), P, N, M, _lib.ptr(init),
+                                         float(max_correspondence_distance), int(max_iteration), float(relative_fitness),
+                                         float(relative_rmse), _lib.ptr(T), _lib.ptr(fit), _lib.ptr(rmse),
+                                         _lib.ptr(iters), _lib.stream_of(src))
+    _lib.check(ok, "houv_icp_refine")
+    return dict(T=T, fitness=fit, inlier_rmse=rmse, iterations=iters)
+
+
 # ---------------------------------------------------------------------------------------------------
 # torch.ops.houv.* registration (PyTorch-ROCm custom ops; the schema marks the in-place outputs)
 # ---------------------------------------------------------------------------------------------------

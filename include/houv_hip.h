@@ -93,6 +93,23 @@ int houv_solve_iterate(const float* src, const float* tgt, int P, int N, int M, 
                        float* out_score, float* out_loss, float* out_R, float* out_T,
                        float* out_grad, float* out_cd, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Point-to-point ICP refinement, one pair per workgroup (BASELINE configs[3]).
+ * Replaces: the per-pair Open3D call of registration/train_ICP.py:137-153
+ *   o3d.registration.registration_icp(pcd, pcd2, threshold=0.02, trans_init,
+ *       TransformationEstimationPointToPoint(), ICPConvergenceCriteria(max_iteration=500))
+ * (open3d==0.9.0, not under /root/reference: its published algorithm is restated; parity unpinned).
+ *   src[P,N,3], tgt[P,M,3]; init [P,16] row-major 4x4 or NULL (identity)
+ *   max_correspondence_distance: a source point corresponds to its NN in tgt iff dist < this
+ *   relative_fitness / relative_rmse: Open3D's ICPConvergenceCriteria defaults are 1e-6 / 1e-6
+ * Outputs: out_T[P,16] row-major 4x4 (bottom row 0,0,0,1; maps src into tgt's frame),
+ *   out_fitness[P] = #correspondences/N, out_rmse[P] = inlier RMSE, out_iters[P] = updates applied (each may be NULL
+ *   except out_T). */
+int houv_icp_refine(const float* src, const float* tgt, int P, int N, int M, const float* init_or_null,
+                    float max_correspondence_distance, int max_iteration, float relative_fitness,
+                    float relative_rmse, float* out_T, float* out_fitness, float* out_rmse, int32_t* out_iters,
+                    void* stream);
+
 /* Pose only (HOUV.forward, houv.py:94-103): params fp32 [n,8] -> R[n,9], T[n,3]; if src != NULL
  * also moved[n,N,3] = src[n,N,3] @ R^T + T. */
 int houv_pose_forward(const float* params, int n, int angle_base, int trans_mode,
