@@ -42,6 +42,10 @@ def parse():
     ap.add_argument("--points", type=int, default=2048)
     ap.add_argument("--kernel", type=int, default=64, help="restarts per pair (houv.py:142 default)")
     ap.add_argument("--iters", type=int, default=200, help="Adam iterations per stage (houv.py:142 default)")
+    ap.add_argument("--icp", action="store_true", help="BASELINE configs[3]: ICP refinement (threshold 0.02, <=500 its) after HOUV")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl = RCCL over xGMI (default); gloo = CPU rehearsal of the N>1 control path")
+    ap.add_argument("--single-device", action="store_true", help="rehearsal only: every rank uses cuda:0")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-chamfer-op", action="store_true")
     return ap.parse_args()
@@ -101,11 +105,16 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (there is no CPU fallback)"
+    if args.single_device:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     from houv_amd import distributed as hd
@@ -135,7 +144,14 @@ def main():
     def step(b):
         s, t, _ = batches[b]
         ans = solve_on_device(s, t)
-        full = hd.gather_transforms(ans, n_total) if world > 1 else ans      # ONE all-gather of [P,12] per rank
+        if args.icp:
+            from houv_amd.icp import icp_refine
+            ans = icp_refine(s, t, ans)
+            ans[:, 3, :] = 0.0                                               # keep the results layout of houv.py:187-195
+        if world > 1:                                                        # ONE all-gather of [P,12] per rank
+            full = hd.gather_transforms(ans if args.backend == "nccl" else ans.cpu(), n_total).to(dev)
+        else:
+            full = ans
         results.append((b, full))
 
     def sync():
@@ -157,7 +173,7 @@ def main():
     log_all, solver.LAUNCH_LOG = solver.LAUNCH_LOG, None
     log = log_all[n_warm_launches:]
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
@@ -187,9 +203,11 @@ def main():
         "kernel_time_share": k_ms * 1e-3 / dt,
         "definition": "algorithmic flops = hypothesis-iterations x 8 sweeps x N*M x 8 flop (SURVEY.md 8d); the fused "
                       "4-metric sweep executes 11 VALU instructions per point pair instead of 4x7, see DESIGN.md",
-        # physical view: VALU issue slots the sweeps need (11.4 lane-ops per 4-metric pair, 2 sweeps) over what the chip has
-        "valu_issue_frac_sweeps": (inst_iters * 2.0 * args.points * args.points * 11.4 / 64 * 2) /
-                                  (k_ms * 1e-3 * 2.4e9 * 1024),
+        # physical view: VALU pipe cycles the two sweeps need per 4-metric point pair and wave = 9 full-rate ops x 2 clk
+        # + 2 v_min3 x 4 clk (half rate, scripts/ubench/valu_rate.hip) + 0.75 clk of sub-tile tracking = 26.75 clk,
+        # over the SIMD-cycles available at the 2.4 GHz peak clock (the chip holds ~2.3 GHz under this load)
+        "valu_pipe_frac_sweeps": (inst_iters * 2.0 * args.points * args.points / 64 * 26.75) /
+                                 (k_ms * 1e-3 * 2.4e9 * 1024),
     }
     out = {
         "metric": "registration pairs/sec (2048-pt partial pairs)", "value": n_total * args.steps / dt,
@@ -200,7 +218,9 @@ def main():
                                f"K={args.kernel} restarts x {args.iters} Adam iterations + retry stages "
                                "(BASELINE configs[1])",
                    "pairs_per_gpu": P, "points": args.points, "kernel": args.kernel, "iters": args.iters,
-                   "parallelism": f"dp{world} (pair shards, one RCCL all-gather of [P,12] per step)"},
+                   "icp_refine": bool(args.icp),
+                   "parallelism": f"dp{world} (pair shards, one {'RCCL' if args.backend == 'nccl' else 'gloo'} "
+                                  "all-gather of [P,12] per step)"},
         "quality": {"mean_rot_err_deg": float(r_err.mean()), "median_rot_err_deg": float(r_err.median()),
                     "mean_trans_err": float(t_err.mean()),
                     "hypothesis_iterations_per_pair": inst_iters / (P * args.steps)},
