@@ -148,6 +148,50 @@ __global__ __launch_bounds__(256) void chamfer_grad_kernel(const float* __restri
   }
 }
 
+// LDS form of the backward pass, one workgroup per batch instance: both directions' contributions are summed in
+// two LDS accumulators (ds_add_f32, no global atomics) and then added to the caller's buffers with coalesced
+// read-modify-writes (the workgroup owns its instance, so the accumulate-into-zeroed contract needs no atomics).
+// HBM-bound: 176 KB per 2048^2 instance.  Used when (N+M)*12 B fits in LDS; chamfer_grad_kernel otherwise.
+__global__ __launch_bounds__(512) void chamfer_grad_lds_kernel(const float* __restrict__ xyz1,
+                                                               const float* __restrict__ xyz2, int N, int M,
+                                                               const float* __restrict__ g1, const float* __restrict__ g2,
+                                                               const int* __restrict__ idx1, const int* __restrict__ idx2,
+                                                               float* __restrict__ gx1, float* __restrict__ gx2) {
+  extern __shared__ float s_acc[];          // [3N] grad of cloud 1, then [3M] grad of cloud 2
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const float* __restrict__ p1 = xyz1 + (size_t)b * N * 3;
+  const float* __restrict__ p2 = xyz2 + (size_t)b * M * 3;
+  float* a1 = s_acc;
+  float* a2 = s_acc + 3 * N;
+  for (int i = tid; i < 3 * (N + M); i += blockDim.x) s_acc[i] = 0.f;
+  __syncthreads();
+  for (int j = tid; j < N; j += blockDim.x) {
+    const int j2 = idx1[(size_t)b * N + j];
+    const float gg = g1[(size_t)b * N + j] * 2.f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float v = gg * (p1[j * 3 + c] - p2[j2 * 3 + c]);
+      atomicAdd(&a1[j * 3 + c], v);
+      atomicAdd(&a2[j2 * 3 + c], -v);
+    }
+  }
+  for (int j = tid; j < M; j += blockDim.x) {
+    const int j2 = idx2[(size_t)b * M + j];
+    const float gg = g2[(size_t)b * M + j] * 2.f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float v = gg * (p2[j * 3 + c] - p1[j2 * 3 + c]);
+      atomicAdd(&a2[j * 3 + c], v);
+      atomicAdd(&a1[j2 * 3 + c], -v);
+    }
+  }
+  __syncthreads();
+  float* o1 = gx1 + (size_t)b * N * 3;
+  float* o2 = gx2 + (size_t)b * M * 3;
+  for (int i = tid; i < 3 * N; i += blockDim.x) o1[i] += a1[i];
+  for (int i = tid; i < 3 * M; i += blockDim.x) o2[i] += a2[i];
+}
+
 }  // namespace
 }  // namespace houv
 
@@ -190,6 +234,16 @@ extern "C" int houv_chamfer_backward(const float* xyz1, const float* xyz2, int B
   if (!xyz1 || !xyz2 || !graddist1 || !graddist2 || !idx1 || !idx2 || !gradxyz1 || !gradxyz2) {
     set_error("houv_chamfer_backward: null pointer");
     return 0;
+  }
+  const size_t lds = (size_t)3 * ((size_t)N + (size_t)M) * sizeof(float);
+  if (lds <= 150 * 1024) {
+    if (hipFuncSetAttribute((const void*)chamfer_grad_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) ==
+        hipSuccess) {
+      chamfer_grad_lds_kernel<<<B, 512, lds, (hipStream_t)stream>>>(xyz1, xyz2, N, M, graddist1, graddist2, idx1, idx2,
+                                                                   gradxyz1, gradxyz2);
+      return check_launch("houv_chamfer_backward") ? 1 : 0;
+    }
+    (void)hipGetLastError();
   }
   const size_t total = (size_t)B * (size_t)(N > M ? N : M);
   size_t blocks = (total + 255) / 256;

@@ -25,6 +25,9 @@ constexpr float kPiF = 3.14159274101257324f;
 
 enum TransMode { kTransHouv = 0, kTransSolve = 1 };
 
+HOUV_HD inline float tsqrt(float x) { return sqrtf(x); }     // correctly rounded (no -ffast-math)
+HOUV_HD inline double tsqrt(double x) { return sqrt(x); }
+
 // Parameter block layout (8 scalars per hypothesis): V[0..2], a, c[0..2], s
 struct Pose {
   float R[9];   // row-major
@@ -115,7 +118,7 @@ HOUV_HD inline void adam_step(T& p, T& m, T& v, T g, int step, double lr, double
   const double bc2 = 1.0 - pow(b2, (double)step);
   const double step_size = lr / bc1;
   const double bc2_sqrt = sqrt(bc2);
-  const T denom = (T)sqrt((double)v) / (T)bc2_sqrt + (T)eps;
+  const T denom = tsqrt(v) / (T)bc2_sqrt + (T)eps;
   p = p - (T)step_size * (m / denom);
 }
 
@@ -141,8 +144,8 @@ HOUV_HD inline void svd3x3(const T H[9], T U[9], T S[3], T V[9]) {
       off += (T)1;
       const T zeta = (b - a) / ((T)2 * g);
       const T az = zeta < 0 ? -zeta : zeta;
-      const T t = (zeta < 0 ? (T)-1 : (T)1) / (az + (T)sqrt((double)((T)1 + zeta * zeta)));
-      const T c = (T)1 / (T)sqrt((double)((T)1 + t * t));
+      const T t = (zeta < 0 ? (T)-1 : (T)1) / (az + tsqrt((T)1 + zeta * zeta));
+      const T c = (T)1 / tsqrt((T)1 + t * t);
       const T s = c * t;
       for (int i = 0; i < 3; ++i) {
         const T bp = B[i * 3 + p], bq = B[i * 3 + q];
@@ -156,7 +159,7 @@ HOUV_HD inline void svd3x3(const T H[9], T U[9], T S[3], T V[9]) {
     if (off == (T)0) break;
   }
   for (int j = 0; j < 3; ++j)
-    S[j] = (T)sqrt((double)(B[0 * 3 + j] * B[0 * 3 + j] + B[1 * 3 + j] * B[1 * 3 + j] + B[2 * 3 + j] * B[2 * 3 + j]));
+    S[j] = tsqrt(B[0 * 3 + j] * B[0 * 3 + j] + B[1 * 3 + j] * B[1 * 3 + j] + B[2 * 3 + j] * B[2 * 3 + j]);
   // sort columns by S descending (3-element network)
   auto swapcol = [&](int x, int y) {
     T ts = S[x]; S[x] = S[y]; S[y] = ts;
@@ -182,7 +185,7 @@ HOUV_HD inline void svd3x3(const T H[9], T U[9], T S[3], T V[9]) {
       T e[3] = {0, 0, 0};
       if (ax <= ay && ax <= az) e[0] = 1; else if (ay <= az) e[1] = 1; else e[2] = 1;
       T w[3] = {y * e[2] - z * e[1], z * e[0] - x * e[2], x * e[1] - y * e[0]};
-      const T n = (T)sqrt((double)(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]));
+      const T n = tsqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
       U[1] = w[0] / n; U[4] = w[1] / n; U[7] = w[2] / n;
     }
   }

@@ -37,12 +37,13 @@ def _oracle_terms(src, tgt, params, base, mode="houv"):
 
 
 @pytest.mark.parametrize("N,M,base,mode", [(128, 128, 0, "houv"), (200, 200, 2, "houv"), (96, 160, 1, "solve"),
-                                           (300, 300, 3, "solve"), (600, 600, 0, "houv"), (1100, 1100, 1, "houv")])
+                                           (300, 300, 3, "solve"), (600, 600, 0, "houv"), (1100, 1100, 1, "houv"),
+                                           (2500, 2500, 2, "houv"), (3000, 2200, 0, "solve")])
 def test_single_forward_backward_vs_oracle(dev, N, M, base, mode):
     """Per-op rung: the 8 Chamfer terms (1e-5, north_star's Chamfer bar), loss, min_1, R/T and the parameter
     gradient (1e-4 relative to the largest component) of one forward from identical parameters."""
     from houv_amd import ops, synthetic
-    P = 30
+    P = 30 if max(N, M) <= 1100 else 8          # the float64 [P,N,M] oracle temp is 50 MB per hypothesis at 2500^2
     src, tgt, _ = synthetic.make_pairs(P, max(N, M), seed=77)
     src, tgt = src[:, :N].contiguous(), tgt[:, :M].contiguous()
     rng = np.random.default_rng(N + base)
@@ -67,7 +68,7 @@ def test_single_forward_backward_vs_oracle(dev, N, M, base, mode):
     # may take the other point of a pair tied to within fp32 rounding (relative margin ~1e-7).  One such flip moves
     # a hypothesis' gradient by one point's share, <= ~2/N, and leaves the loss unchanged: allow it on at most one
     # hypothesis of the 30; everything else must agree to 2e-4 of the gradient's largest component.
-    assert (err > 2e-4).sum() <= 1, err
+    assert (err > 2e-4).sum() <= (1 if max(N, M) <= 1100 else 2), err
     assert err.max() < 3.0 / min(N, M), err
 
 
@@ -170,3 +171,34 @@ def test_topk_size_out_of_range_is_an_error(dev):
                          angle_base=0, trans_mode=1, use_views=False, f64_params=True, lr=0.1)
     with pytest.raises(IndexError):
         solver.houv_init_params(25)                                   # houv.py:47-51 has no bounds check
+
+
+def test_full_size_properties_cfg2_shape(dev):
+    """BASELINE cfg2-shaped problem (2048x2048 points, K=64): properties that need no CPU oracle.
+    (i) pairs are independent: permuting the pair list permutes the results BIT-exactly (same batch size, hence the
+    same 1/(P*K) loss scale); (ii) the returned R are rotations and T obey the 0..0.25 magnitude window of
+    houv.py:99; (iii) scores are finite and positive; (iv) more iterations do not increase the best score of most pairs."""
+    from houv_amd import solver, synthetic
+    P, K, N = 16, 64, 2048
+    src, tgt, _ = synthetic.make_pairs(P, N, seed=404)
+    src, tgt = src.to(dev), tgt.to(dev)
+    p0 = solver.houv_init_params(P * K)
+    kw = dict(angle_base=0, trans_mode=0, use_views=True, f64_params=False, lr=0.01)
+    out, st = solver.run_stage(src, tgt, p0, K, 6, **kw)
+    perm = torch.randperm(P, generator=torch.Generator().manual_seed(1)).to(dev)
+    # hypothesis h of pair p keeps its own initial parameters: permute the parameter blocks along with the pairs
+    p0p = torch.as_tensor(p0).reshape(P, K, 8)[perm.cpu()].reshape(P * K, 8)
+    outp, stp = solver.run_stage(src[perm].contiguous(), tgt[perm].contiguous(), p0p, K, 6, **kw)
+    for key in ("score", "loss", "R", "T"):
+        a = out[key].reshape(P, K, -1)[perm].reshape(outp[key].shape)
+        assert torch.equal(a, outp[key]), key
+    assert torch.equal(st.reshape(P, K, 24)[perm].reshape(P * K, 24), stp)
+    R = out["R"]
+    eye = torch.eye(3, device=dev).expand_as(R)
+    assert float((R @ R.transpose(1, 2) - eye).abs().max()) < 1e-5 and float((torch.det(R) - 1).abs().max()) < 1e-5
+    tn = out["T"].norm(dim=1)
+    assert float(tn.max()) <= 0.25 + 1e-6 and float(tn.min()) >= 0.0
+    assert bool(torch.isfinite(out["score"]).all()) and float(out["score"].min()) > 0
+    out2, _ = solver.run_stage(src, tgt, p0, K, 40, **kw)
+    better = (out2["score"].reshape(P, K).min(1)[0] <= out["score"].reshape(P, K).min(1)[0]).float().mean()
+    assert float(better) >= 0.75
