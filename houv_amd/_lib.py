@@ -28,6 +28,15 @@ _SIGNATURES = {
                                           _int, _int, _dbl, _dbl, _dbl, _dbl, _flt, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f,
                                           _c_f]),
     "houv_icp_refine": (ctypes.c_int, [_c_f, _c_f, _int, _int, _int, _c_f, _flt, _int, _flt, _flt, _c_f, _c_f, _c_f, _c_f, _c_f]),
+    "houv_knn": (ctypes.c_int, [_c_f, _int, _int, _int, _c_f, _c_f]),
+    "houv_edgeconv1": (ctypes.c_int, [_c_f, _c_f, _int, _int, _int, _c_f, _c_f, _c_f, _c_f, _c_f]),
+    "houv_max_over_k": (ctypes.c_int, [_c_f, ctypes.c_longlong, _int, _int, _c_f, _int, _c_f]),
+    "houv_gemm_f32": (ctypes.c_int, [_c_f, _c_f, _c_f, _int, _int, _int, _int, _int, _int, _int, _int, _int] +
+                      [ctypes.c_longlong] * 6 + [_flt, _c_f, _c_f, _c_f, _int, ctypes.c_longlong, ctypes.c_longlong,
+                                                 _int, _c_f]),
+    "houv_layernorm": (ctypes.c_int, [_c_f, ctypes.c_longlong, _int, _c_f, _c_f, _flt, _c_f, _c_f, _c_f]),
+    "houv_softmax_rows": (ctypes.c_int, [_c_f, ctypes.c_longlong, _int, _c_f]),
+    "houv_softmax_corr": (ctypes.c_int, [_c_f, _int, _int, _int, _c_f, _c_f, _c_f]),
     "houv_pose_forward": (ctypes.c_int, [_c_f, _int, _int, _int, _c_f, _int, _c_f, _c_f, _c_f, _c_f]),
 }
 
@@ -91,4 +100,16 @@ def require_gpu(*tensors, dtype=None):
             raise HouvHipError("houv_amd ops need contiguous tensors")
     dev = [t.device for t in tensors if t is not None]
     if any(d != dev[0] for d in dev):
+        raise HouvHipError("all tensors must live on the same device")
+
+
+def require_gpu_any(*tensors):
+    """Like require_gpu but allows strided (row-major, inner-contiguous) views."""
+    ts = [t for t in tensors if t is not None]
+    for t in ts:
+        if not t.is_cuda:
+            raise HouvHipError("houv_amd ops run on an MI355X only: got a CPU tensor (there is no CPU fallback)")
+        if t.dtype != torch.float32:
+            raise HouvHipError(f"expected float32, got {t.dtype}")
+    if any(t.device != ts[0].device for t in ts):
         raise HouvHipError("all tensors must live on the same device")

@@ -1,0 +1,198 @@
+// gemm.hip -- fp32 MFMA GEMM with fused epilogue for the DCP head (BASELINE configs[4]).
+//
+// The DCP feature head (registration/models/dcp.py:269-381) is GEMM-shaped: 1x1 convolutions of the DGCNN
+// (:272-276), the Transformer's linear layers / attention products (:26-32, :198-243) and the soft-correspondence
+// scores (:345-346).  The reference computes in fp32, and so does this kernel: v_mfma_f32_32x32x2_f32 is an exact
+// k-ordered fmaf chain at the fp32 vector rate (157 TFLOP/s peak), so parity with the reference needs no mixed
+// precision argument.
+//
+//   C[m,n] = epilogue( alpha * sum_k A[m,k] * Bop[k,n] )        batched over blockIdx.z = (zo, zi)
+//   BT = true : B is [N,K] row-major (nn.Linear / conv weight [out,in], K^T of attention) -> C = A B^T
+//   BT = false: B is [K,N] row-major (P V of attention)                                  -> C = A B
+//   epilogue  : v = alpha*acc; v = v*scale[n] + shift[n] (eval BatchNorm folded) | v += shift[n] (bias);
+//               v += residual[m,n]; v = max(v,0)
+// Tile 128 x BN x 16, 256 threads = 4 waves (2x2), each wave a 64 x BN/2 block of 32x32 MFMA tiles; LDS tiles are
+// stored k-major so an MFMA operand fetch is a conflict-free ds_read_b32 (lanes 0-31: 32 consecutive rows at k,
+// lanes 32-63: the same rows at k+1); the next k-tile is prefetched into registers while the current one is
+// multiplied.
+#include "../../include/houv_hip.h"
+#include "houv_common.h"
+
+namespace houv {
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct GemmArgs {
+  const float* A; const float* B; float* C;
+  int M, N, K, lda, ldb, ldc;
+  int inner;                                   // blockIdx.z = zo * inner + zi
+  long long sAo, sAi, sBo, sBi, sCo, sCi;      // element strides of the two batch levels
+  float alpha;
+  const float* scale; const float* shift;      // per output column n (may be null)
+  const float* residual; int ldr; long long sRo, sRi;
+  int relu;
+};
+
+constexpr int BM = 128, BK = 16;
+
+__device__ __forceinline__ float4 load4_guarded(const float* __restrict__ p, int valid, bool vec_ok) {
+  // up to 4 consecutive floats starting at p; `valid` of them exist (0..4)
+  if (vec_ok && valid >= 4) return *reinterpret_cast<const float4*>(p);
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (valid > 0) v.x = p[0];
+  if (valid > 1) v.y = p[1];
+  if (valid > 2) v.z = p[2];
+  if (valid > 3) v.w = p[3];
+  return v;
+}
+
+template <int BN, bool BT>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
+  constexpr int LDA = BM + 1;                         // k-major tiles, +1 breaks the transposing writes' conflicts
+  constexpr int LDB = BT ? (BN + 1) : (BN + 4);       // the [K,N] form is written with 16-byte stores
+  constexpr int NI = BN / 64;                         // 32-wide MFMA tiles per wave along N
+  constexpr int BREG = BT ? (BN * BK / 4 / 256) : (BN * BK / 4 / 256);
+  __shared__ float As[BK * LDA];
+  __shared__ __attribute__((aligned(16))) float Bs[BK * LDB];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int zo = blockIdx.z / g.inner, zi = blockIdx.z - zo * g.inner;
+  const float* __restrict__ A = g.A + zo * g.sAo + zi * g.sAi;
+  const float* __restrict__ B = g.B + zo * g.sBo + zi * g.sBi;
+  float* __restrict__ C = g.C + zo * g.sCo + zi * g.sCi;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const bool vecA = ((g.lda & 3) == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0);
+  const bool vecB = ((g.ldb & 3) == 0) && ((reinterpret_cast<uintptr_t>(B) & 15) == 0);
+
+  f32x16 acc[2][NI];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  float4 ra[2], rb[BREG];
+  auto fetch = [&](int k0) {
+    // A tile: 128 rows x 16 k = 512 float4; thread t -> row t/4 + 64 i, k-quad (t%4)*4
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int row = m0 + (tid >> 2) + 64 * i, k = k0 + (tid & 3) * 4;
+      ra[i] = (row < g.M) ? load4_guarded(A + (size_t)row * g.lda + k, g.K - k, vecA) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if constexpr (BT) {   // B[n][k]: same pattern as A
+#pragma unroll
+      for (int i = 0; i < BREG; ++i) {
+        const int col = n0 + (tid >> 2) + 64 * i, k = k0 + (tid & 3) * 4;
+        rb[i] = (col < g.N) ? load4_guarded(B + (size_t)col * g.ldb + k, g.K - k, vecB) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    } else {              // B[k][n]: 16 k-rows x BN cols; thread t -> k = t / (BN/4) + (256/(BN/4)) i, n-quad
+      constexpr int QPR = BN / 4, RPP = 256 / QPR;
+#pragma unroll
+      for (int i = 0; i < BREG; ++i) {
+        const int k = k0 + tid / QPR + RPP * i, col = n0 + (tid % QPR) * 4;
+        rb[i] = (k < g.K) ? load4_guarded(B + (size_t)k * g.ldb + col, g.N - col, vecB) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+  };
+  auto stage = [&]() {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int r = (tid >> 2) + 64 * i, k = (tid & 3) * 4;
+      As[(k + 0) * LDA + r] = ra[i].x; As[(k + 1) * LDA + r] = ra[i].y;
+      As[(k + 2) * LDA + r] = ra[i].z; As[(k + 3) * LDA + r] = ra[i].w;
+    }
+    if constexpr (BT) {
+#pragma unroll
+      for (int i = 0; i < BREG; ++i) {
+        const int c = (tid >> 2) + 64 * i, k = (tid & 3) * 4;
+        Bs[(k + 0) * LDB + c] = rb[i].x; Bs[(k + 1) * LDB + c] = rb[i].y;
+        Bs[(k + 2) * LDB + c] = rb[i].z; Bs[(k + 3) * LDB + c] = rb[i].w;
+      }
+    } else {
+      constexpr int QPR = BN / 4, RPP = 256 / QPR;
+#pragma unroll
+      for (int i = 0; i < BREG; ++i) {
+        const int k = tid / QPR + RPP * i, c = (tid % QPR) * 4;
+        *reinterpret_cast<float4*>(&Bs[k * LDB + c]) = rb[i];
+      }
+    }
+  };
+
+  fetch(0);
+  for (int k0 = 0; k0 < g.K; k0 += BK) {
+    __syncthreads();          // previous tile fully consumed
+    stage();
+    __syncthreads();
+    if (k0 + BK < g.K) fetch(k0 + BK);     // prefetch the next tile into registers under the MFMAs
+    const int kh = lane >> 5, rl = lane & 31;
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 2) {
+      float a[2], b[NI];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) a[i] = As[(kk + kh) * LDA + wm * 64 + i * 32 + rl];
+#pragma unroll
+      for (int j = 0; j < NI; ++j) b[j] = Bs[(kk + kh) * LDB + wn * (BN / 2) + j * 32 + rl];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+  }
+
+  // epilogue: C/D map of the 32x32 tile: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+  const float* __restrict__ Rsd = g.residual ? g.residual + zo * g.sRo + zi * g.sRi : nullptr;
+#pragma unroll
+  for (int j = 0; j < NI; ++j) {
+    const int col = n0 + wn * (BN / 2) + j * 32 + (lane & 31);
+    if (col >= g.N) continue;
+    const float sc = g.scale ? g.scale[col] : 1.0f;
+    const float sh = g.shift ? g.shift[col] : 0.0f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (row >= g.M) continue;
+        float v = acc[i][j][r] * g.alpha;
+        v = v * sc + sh;
+        if (Rsd) v += Rsd[(size_t)row * g.ldr + col];
+        if (g.relu) v = fmaxf(v, 0.f);
+        C[(size_t)row * g.ldc + col] = v;
+      }
+    }
+  }
+}
+
+}  // namespace
+}  // namespace houv
+
+// Public op-level entry (used by houv_dcp_forward and by the tests).  trans_b: 1 -> B is [N,K] row-major (C = A B^T),
+// 0 -> B is [K,N] row-major (C = A B).  batch = outer*inner problems; element strides per level.
+extern "C" int houv_gemm_f32(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
+                             int trans_b, int outer, int inner, long long sAo, long long sAi, long long sBo,
+                             long long sBi, long long sCo, long long sCi, float alpha, const float* scale_or_null,
+                             const float* shift_or_null, const float* residual_or_null, int ldr, long long sRo,
+                             long long sRi, int relu, void* stream) {
+  using namespace houv;
+  if (M <= 0 || N <= 0 || K <= 0 || outer <= 0 || inner <= 0 || !A || !B || !C || lda < K || ldc < N ||
+      (trans_b ? ldb < K : ldb < N) || (long long)outer * inner > 65535) {
+    set_error("houv_gemm_f32: bad argument M=%d N=%d K=%d lda=%d ldb=%d ldc=%d batch=%dx%d", M, N, K, lda, ldb, ldc,
+              outer, inner);
+    return 0;
+  }
+  GemmArgs g{A, B, C, M, N, K, lda, ldb, ldc, inner, sAo, sAi, sBo, sBi, sCo, sCi, alpha, scale_or_null, shift_or_null,
+             residual_or_null, ldr, sRo, sRi, relu};
+  hipStream_t s = (hipStream_t)stream;
+  const bool narrow = N <= 64;
+  dim3 grid((N + (narrow ? 64 : 128) - 1) / (narrow ? 64 : 128), (M + BM - 1) / BM, outer * inner);
+  if (narrow) {
+    if (trans_b) gemm_f32_kernel<64, true><<<grid, 256, 0, s>>>(g);
+    else gemm_f32_kernel<64, false><<<grid, 256, 0, s>>>(g);
+  } else {
+    if (trans_b) gemm_f32_kernel<128, true><<<grid, 256, 0, s>>>(g);
+    else gemm_f32_kernel<128, false><<<grid, 256, 0, s>>>(g);
+  }
+  return check_launch("houv_gemm_f32") ? 1 : 0;
+}

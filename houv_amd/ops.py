@@ -173,3 +173,112 @@ def register_torch_ops():
     lib.impl("kabsch", kabsch, "CUDA")
     register_torch_ops._lib = lib      # keep alive
     _registered = True
+
+
+# ---------------------------------------------------------------------------------------------------
+# DCP feature-head building blocks (houv_knn, houv_edgeconv1, houv_max_over_k, houv_gemm_f32, houv_layernorm,
+# houv_softmax_rows, houv_softmax_corr): thin wrappers; shapes are checked, buffers are allocated with torch.
+# ---------------------------------------------------------------------------------------------------
+def knn(xyz, k):
+    """xyz[B,N,3] -> idx[B,N,k] int32, nearest first, self included (dcp.py:35-42)."""
+    _lib.require_gpu(xyz); _want(xyz, _F32, "xyz")
+    B, N, _ = xyz.shape
+    idx = torch.empty((B, N, k), dtype=_I32, device=xyz.device)
+    with torch.cuda.device(xyz.device):
+        ok = _lib.load().houv_knn(_lib.ptr(xyz), B, N, int(k), _lib.ptr(idx), _lib.stream_of(xyz))
+    _lib.check(ok, "houv_knn")
+    return idx
+
+
+def edgeconv1(xyz, idx, W, scale, shift):
+    """-> act[B*N*k, 64] = relu(scale * conv1(cat(neighbour, centre)) + shift)."""
+    _lib.require_gpu(xyz, idx, W, scale, shift)
+    B, N, k = idx.shape
+    out = torch.empty((B * N * k, 64), dtype=_F32, device=xyz.device)
+    with torch.cuda.device(xyz.device):
+        ok = _lib.load().houv_edgeconv1(_lib.ptr(xyz), _lib.ptr(idx), B, N, k, _lib.ptr(W), _lib.ptr(scale),
+                                        _lib.ptr(shift), _lib.ptr(out), _lib.stream_of(xyz))
+    _lib.check(ok, "houv_edgeconv1")
+    return out
+
+
+def max_over_k(act, k, out, col0):
+    """out[:, col0:col0+C] = max over groups of k consecutive rows of act[npts*k, C]."""
+    _lib.require_gpu(act, out)
+    C = act.shape[1]
+    npts = act.shape[0] // k
+    view = out[:, col0:col0 + C]
+    with torch.cuda.device(act.device):
+        ok = _lib.load().houv_max_over_k(_lib.ptr(act), npts, int(k), C, ctypes_ptr(view), out.stride(0),
+                                         _lib.stream_of(act))
+    _lib.check(ok, "houv_max_over_k")
+
+
+def ctypes_ptr(t):
+    import ctypes
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def gemm(A, B, C=None, *, trans_b=True, alpha=1.0, scale=None, shift=None, residual=None, relu=False):
+    """2-D or batched (3-/4-D leading dims = (outer[, inner])) fp32 GEMM on the MFMA kernel.
+    A[..., M, K]; B[..., N, K] if trans_b else B[..., K, N]; returns C[..., M, N].  Inner-most dims may be strided
+    row-major views (row stride = lda), which is how per-head attention operands are addressed without copies."""
+    _lib.require_gpu_any(A, B, C, scale, shift, residual)
+    lead = A.shape[:-2]
+    M, K = A.shape[-2:]
+    N = B.shape[-2] if trans_b else B.shape[-1]
+    if C is None:
+        C = torch.empty(lead + (M, N), dtype=_F32, device=A.device)
+    outer = lead[0] if len(lead) >= 1 else 1
+    inner = lead[1] if len(lead) == 2 else 1
+
+    def strides(t):
+        ld = t.stride(-2)
+        assert t.stride(-1) == 1, "innermost dimension must be contiguous"
+        so = t.stride(0) if len(lead) >= 1 else 0
+        si = t.stride(1) if len(lead) == 2 else 0
+        return ld, so, si
+    lda, sAo, sAi = strides(A)
+    ldb, sBo, sBi = strides(B)
+    ldc, sCo, sCi = strides(C)
+    ldr, sRo, sRi = strides(residual) if residual is not None else (0, 0, 0)
+    with torch.cuda.device(A.device):
+        ok = _lib.load().houv_gemm_f32(ctypes_ptr(A), ctypes_ptr(B), ctypes_ptr(C), M, N, K, lda, ldb, ldc,
+                                       int(bool(trans_b)), outer, inner, sAo, sAi, sBo, sBi, sCo, sCi, float(alpha),
+                                       _lib.ptr(scale), _lib.ptr(shift),
+                                       None if residual is None else ctypes_ptr(residual), ldr, sRo, sRi,
+                                       int(bool(relu)), _lib.stream_of(A))
+    _lib.check(ok, "houv_gemm_f32")
+    return C
+
+
+def layernorm(x, a, b, eps=1e-6, residual=None):
+    _lib.require_gpu(x, a, b, residual)
+    D = x.shape[-1]
+    rows = x.numel() // D
+    out = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        ok = _lib.load().houv_layernorm(_lib.ptr(x), rows, D, _lib.ptr(a), _lib.ptr(b), float(eps), _lib.ptr(residual),
+                                        _lib.ptr(out), _lib.stream_of(x))
+    _lib.check(ok, "houv_layernorm")
+    return out
+
+
+def softmax_rows_(x):
+    _lib.require_gpu(x)
+    L = x.shape[-1]
+    with torch.cuda.device(x.device):
+        ok = _lib.load().houv_softmax_rows(_lib.ptr(x), x.numel() // L, L, _lib.stream_of(x))
+    _lib.check(ok, "houv_softmax_rows")
+    return x
+
+
+def softmax_corr(scores, pts):
+    """scores[P,N,M], pts[P,M,3] -> corr[P,3,N] = pts^T softmax(scores)^T."""
+    _lib.require_gpu(scores, pts)
+    P, N, M = scores.shape
+    corr = torch.empty((P, 3, N), dtype=_F32, device=scores.device)
+    with torch.cuda.device(scores.device):
+        ok = _lib.load().houv_softmax_corr(_lib.ptr(scores), P, N, M, _lib.ptr(pts), _lib.ptr(corr), _lib.stream_of(scores))
+    _lib.check(ok, "houv_softmax_corr")
+    return corr

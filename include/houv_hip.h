@@ -110,6 +110,42 @@ int houv_icp_refine(const float* src, const float* tgt, int P, int N, int M, con
                     float relative_rmse, float* out_T, float* out_fitness, float* out_rmse, int32_t* out_iters,
                     void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * DCP feature head building blocks (BASELINE configs[4]): registration/models/dcp.py in fp32,
+ * inference (eval-mode BatchNorm folded into per-channel scale/shift by the caller).  The model-level forward
+ * (DGCNN -> Transformer -> soft correspondences -> houv_kabsch) is composed from these in houv_amd/models/dcp.py.
+ * Layout convention: activations are row-major [rows, channels] ("token-major"), clouds [B,N,3]. */
+
+/* dcp.py:35-42 `knn`: idx[B,N,k] = the k nearest points of xyz[B,N,3] to each point, nearest first, self included.
+ * k in {1,3,8,16,20}. */
+int houv_knn(const float* xyz, int B, int N, int k, int32_t* idx, void* stream);
+
+/* dcp.py:44-66 + :285: edge feature cat(neighbour, centre)[6] -> relu(scale*(W[64,6] f) + shift) for every (point, neighbour):
+ * out[(B*N*k), 64]. */
+int houv_edgeconv1(const float* xyz, const int32_t* idx, int B, int N, int k, const float* W, const float* scale,
+                   const float* shift, float* out, void* stream);
+
+/* dcp.py:287/290/293/296 `x.max(dim=-1)`: out[p*ldo + c] = max_j act[(p*k+j)*C + c], p < npts (C, ldo multiples of 4). */
+int houv_max_over_k(const float* act, long long npts, int k, int C, float* out, int ldo, void* stream);
+
+/* fp32 MFMA GEMM with fused epilogue (1x1 conv / nn.Linear / attention products):
+ *   C = relu?( (alpha * A[M,K] op(B)) * scale[n] + shift[n] + residual[m,n] ),  trans_b=1: B is [N,K] (C = A B^T), 0: [K,N].
+ * Batched over outer*inner problems with element strides (s?o, s?i).  scale/shift/residual may be NULL. */
+int houv_gemm_f32(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
+                  int trans_b, int outer, int inner, long long sAo, long long sAi, long long sBo, long long sBi,
+                  long long sCo, long long sCi, float alpha, const float* scale_or_null, const float* shift_or_null,
+                  const float* residual_or_null, int ldr, long long sRo, long long sRi, int relu, void* stream);
+
+/* dcp.py:144-154 LayerNorm: out = a*(x-mean)/(std+eps)+b over the last dim D (torch.std: unbiased) [+ residual]. */
+int houv_layernorm(const float* x, long long rows, int D, const float* a, const float* b, float eps,
+                   const float* residual_or_null, float* out, void* stream);
+
+/* dcp.py:31: x[rows,L] <- softmax over L, in place. */
+int houv_softmax_rows(float* x, long long rows, int L, void* stream);
+
+/* dcp.py:346-348: corr[P,3,N] = pts[P,M,3]^T . softmax(scores[P,N,M])^T, one pass per score row. */
+int houv_softmax_corr(const float* scores, int P, int N, int M, const float* pts, float* corr, void* stream);
+
 /* Pose only (HOUV.forward, houv.py:94-103): params fp32 [n,8] -> R[n,9], T[n,3]; if src != NULL
  * also moved[n,N,3] = src[n,N,3] @ R^T + T. */
 int houv_pose_forward(const float* params, int n, int angle_base, int trans_mode,

@@ -1,0 +1,146 @@
+"""GPU parity of the DCP feature head (BASELINE configs[4]): building blocks against torch on the same
+inputs, and the whole model against golden vectors from the reference's dcp.py (tests/golden/make_golden_dcp.py;
+seeded random weights from tests/golden/dcp_weights.py -- the repository ships no trained DCP checkpoint)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+import dcp_weights  # noqa: E402
+
+T = torch.tensor
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+@pytest.mark.parametrize("B,N,k", [(2, 48, 20), (3, 300, 20), (1, 2048, 20), (2, 1500, 8), (2, 64, 1)])
+def test_knn_matches_reference_formula(dev, B, N, k):
+    from houv_amd import ops
+    gen = torch.Generator().manual_seed(N + k)
+    x = torch.rand(B, N, 3, generator=gen)
+    idx = ops.knn(x.to(dev), k).cpu().long()
+    # dcp.py:35-42 in float64: -|xi|^2 + 2 xi.xj - |xj|^2, topk largest
+    xd = x.double().transpose(1, 2)
+    pd = -(xd ** 2).sum(1, keepdim=True).transpose(2, 1) + 2 * xd.transpose(2, 1) @ xd - (xd ** 2).sum(1, keepdim=True)
+    ref = pd.topk(k=k, dim=-1)[1]
+    same = (idx.sort(-1)[0] == ref.sort(-1)[0]).all(-1)
+    assert same.float().mean() > 0.999                      # neighbour SETS agree (fp32 near-ties at the k-th place aside)
+    assert (idx[..., 0] == torch.arange(N)).all()           # nearest = the point itself
+    d = ((x.unsqueeze(2) - torch.gather(x.unsqueeze(1).expand(B, N, N, 3), 2, idx.unsqueeze(-1).expand(B, N, k, 3))) ** 2).sum(-1)
+    assert (d[..., 1:] >= d[..., :-1] - 1e-7).all()        # nearest first
+
+
+@pytest.mark.parametrize("M,N,K,tb", [(128, 128, 64, True), (300, 70, 130, True), (1000, 512, 512, True),
+                                     (257, 64, 64, True), (200, 128, 333, False), (64, 96, 48, False), (5, 3, 7, True)])
+def test_gemm_plain(dev, M, N, K, tb):
+    from houv_amd import ops
+    gen = torch.Generator().manual_seed(M * 7 + N)
+    A = torch.randn(M, K, generator=gen).to(dev)
+    B = (torch.randn(N, K, generator=gen) if tb else torch.randn(K, N, generator=gen)).to(dev)
+    C = ops.gemm(A, B, trans_b=tb)
+    ref = (A.double() @ (B.double().t() if tb else B.double())).float()
+    np.testing.assert_allclose(C.cpu().numpy(), ref.cpu().numpy(), rtol=2e-5, atol=2e-5 * np.sqrt(K))
+    # A = I with an ASYMMETRIC B catches a swapped row/col map in the C write (cdna_hip_programming.md section 3)
+    if M == K and tb:
+        I = torch.eye(M, device=dev)
+        np.testing.assert_array_equal(ops.gemm(I, B, trans_b=True).cpu().numpy(), B.t().cpu().numpy())
+
+
+def test_gemm_epilogue_and_batched_strided(dev):
+    from houv_amd import ops
+    gen = torch.Generator().manual_seed(5)
+    A = torch.randn(333, 64, generator=gen).to(dev); W = torch.randn(128, 64, generator=gen).to(dev)
+    sc = torch.rand(128, generator=gen).to(dev) + 0.5; sh = torch.randn(128, generator=gen).to(dev)
+    R = torch.randn(333, 128, generator=gen).to(dev)
+    C = ops.gemm(A, W, scale=sc, shift=sh, residual=R, relu=True, alpha=0.5)
+    ref = torch.relu((0.5 * (A.double() @ W.double().t())) * sc.double() + sh.double() + R.double()).float()
+    np.testing.assert_allclose(C.cpu().numpy(), ref.cpu().numpy(), rtol=2e-5, atol=1e-4)
+    C = ops.gemm(A, W, shift=sh)                                   # bias only
+    np.testing.assert_allclose(C.cpu().numpy(), (A.double() @ W.double().t() + sh.double()).float().cpu().numpy(), rtol=2e-5, atol=1e-4)
+    # attention-shaped: per-head strided views, both products
+    P, H, Nq, Nk, dk = 2, 4, 150, 170, 128
+    Q = torch.randn(P, Nq, H, dk, generator=gen).to(dev); Kt = torch.randn(P, Nk, H, dk, generator=gen).to(dev)
+    V = torch.randn(P, Nk, H, dk, generator=gen).to(dev)
+    S = ops.gemm(Q.permute(0, 2, 1, 3), Kt.permute(0, 2, 1, 3), trans_b=True, alpha=0.25)
+    refS = 0.25 * torch.einsum("pqhd,pkhd->phqk", Q.double(), Kt.double())
+    np.testing.assert_allclose(S.cpu().numpy(), refS.float().cpu().numpy(), rtol=2e-5, atol=2e-4)
+    ctx = torch.zeros(P, Nq, H, dk, device=dev)
+    ops.gemm(S, V.permute(0, 2, 1, 3), ctx.permute(0, 2, 1, 3), trans_b=False)
+    refC = torch.einsum("phqk,pkhd->pqhd", S.double(), V.double())
+    np.testing.assert_allclose(ctx.cpu().numpy(), refC.float().cpu().numpy(), rtol=2e-5, atol=2e-3)
+
+
+def test_layernorm_softmax_corr_maxk(dev):
+    from houv_amd import ops
+    gen = torch.Generator().manual_seed(9)
+    x = torch.randn(37, 512, generator=gen).to(dev); a = torch.rand(512, generator=gen).to(dev); b = torch.randn(512, generator=gen).to(dev)
+    r = torch.randn(37, 512, generator=gen).to(dev)
+    ref = a * (x - x.mean(-1, keepdim=True)) / (x.std(-1, keepdim=True) + 1e-6) + b      # dcp.py:151-154
+    np.testing.assert_allclose(ops.layernorm(x, a, b).cpu().numpy(), ref.cpu().numpy(), atol=2e-6, rtol=1e-5)
+    np.testing.assert_allclose(ops.layernorm(x, a, b, residual=r).cpu().numpy(), (ref + r).cpu().numpy(), atol=3e-6, rtol=1e-5)
+    s = (torch.randn(3, 50, 77, generator=gen) * 4).to(dev)
+    want = torch.softmax(s, dim=-1)
+    pts = torch.randn(3, 77, 3, generator=gen).to(dev)
+    corr = ops.softmax_corr(s, pts)
+    np.testing.assert_allclose(corr.cpu().numpy(), torch.matmul(pts.transpose(1, 2), want.transpose(2, 1)).cpu().numpy(), atol=2e-6)
+    np.testing.assert_allclose(ops.softmax_rows_(s.clone()).cpu().numpy(), want.cpu().numpy(), atol=1e-6)
+    act = torch.randn(11 * 20, 64, generator=gen).to(dev)
+    out = torch.zeros(11, 512, device=dev)
+    ops.max_over_k(act, 20, out, 64)
+    np.testing.assert_array_equal(out[:, 64:128].cpu().numpy(), act.view(11, 20, 64).max(1)[0].cpu().numpy())
+    assert float(out[:, :64].abs().max()) == 0 and float(out[:, 128:].abs().max()) == 0
+
+
+def _model(dev):
+    from houv_amd.models.dcp import Model
+    net = Model(args=None)
+    state = {k: T(v) for k, v in dcp_weights.make_state(1234).items()}
+    missing, unexpected = net.load_state_dict(state, strict=False)
+    assert not unexpected and all(m.endswith("num_batches_tracked") or m == "head.reflect" for m in missing), (missing, unexpected)
+    return net.to(dev)
+
+
+def test_state_dict_names_equal_reference():
+    from houv_amd.models.dcp import Model
+    mine = {k for k in Model(None).state_dict() if not k.endswith("num_batches_tracked") and k != "head.reflect"}
+    assert mine == {n for n, _ in dcp_weights.spec()}
+
+
+def test_model_vs_reference_golden(golden, dev):
+    g = golden("g9_dcp.npz")
+    net = _model(dev)
+    # small case: every intermediate tensor
+    s, t = T(g["small_src"]).to(dev), T(g["small_tgt"]).to(dev)
+    with torch.no_grad():
+        es, et = net.emb_nn(s), net.emb_nn(t)
+        np.testing.assert_allclose(es.transpose(1, 2).cpu().numpy(), g["small_emb_src"], atol=2e-4, rtol=1e-4)
+        np.testing.assert_allclose(et.transpose(1, 2).cpu().numpy(), g["small_emb_tgt"], atol=2e-4, rtol=1e-4)
+        ed = net.pointer.model
+        zero_t, zero_s = torch.zeros_like(et), torch.zeros_like(es)
+        pt = ed(es, et, add_to=zero_t); ps = ed(et, es, add_to=zero_s)
+        np.testing.assert_allclose(pt.transpose(1, 2).cpu().numpy(), g["small_ptr_tgt"], atol=1e-3, rtol=1e-3)
+        np.testing.assert_allclose(ps.transpose(1, 2).cpu().numpy(), g["small_ptr_src"], atol=1e-3, rtol=1e-3)
+    for name in ("small", "mid"):
+        s, t = T(g[f"{name}_src"]).to(dev), T(g[f"{name}_tgt"]).to(dev)
+        T12 = net(s, t)
+        np.testing.assert_allclose(T12.cpu().numpy(), g[f"{name}_T12"], atol=2e-3)
+        assert np.array_equal(T12[:, 3].cpu().numpy(), np.broadcast_to([0, 0, 0, 1], (2, 4)).astype(np.float32))
+    with torch.no_grad():
+        es = net.emb_nn(T(g["mid_src"]).to(dev))
+    np.testing.assert_allclose(es.transpose(1, 2).cpu().numpy()[:, ::8, ::8], g["mid_emb_src_s"], atol=2e-4, rtol=1e-4)
+
+
+def test_model_with_T_gt_returns_reference_tuple(dev):
+    from houv_amd import synthetic
+    net = _model(dev)
+    src, tgt, pose = synthetic.make_pairs(3, 128, seed=8)
+    out = net(src.to(dev), tgt.to(dev), pose.to(dev))
+    assert len(out) == 5 and out[1].shape == (3,) and out[0].ndim == 0
