@@ -42,6 +42,8 @@ def parse():
     ap.add_argument("--points", type=int, default=2048)
     ap.add_argument("--kernel", type=int, default=64, help="restarts per pair (houv.py:142 default)")
     ap.add_argument("--iters", type=int, default=200, help="Adam iterations per stage (houv.py:142 default)")
+    ap.add_argument("--dcp", action="store_true",
+                    help="BASELINE configs[4]: DCP feature head (fp32 MFMA GEMMs, random-init weights) + HOUV loss of its answer")
     ap.add_argument("--icp", action="store_true", help="BASELINE configs[3]: ICP refinement (threshold 0.02, <=500 its) after HOUV")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (default); gloo = CPU rehearsal of the N>1 control path")
@@ -99,6 +101,72 @@ def chamfer_op_probe(dev, points):
             "algorithmic_GBps": byts / t / 1e9, "frac_hbm_peak": byts / t / 1e9 / HBM_PEAK_GBPS}
 
 
+def bench_dcp(args, dev, world, rank):
+    """configs[4]: one step = DCP forward (DGCNN + Transformer pointer + SVD head) over the batch, then the HOUV robust
+    Chamfer loss (Predict_loss, houv.py:209-222) of the source cloud moved by DCP's answer.  Weights are random-init
+    (the reference ships no checkpoint), so only throughput and the loss plumbing are meaningful, not accuracy."""
+    from houv_amd import ops, synthetic
+    from houv_amd.models.dcp import Model
+    from houv_amd.models.houv import Predict_loss
+    P = args.pairs
+    torch.manual_seed(2021)
+    net = Model(None, pairs_per_chunk=16).to(dev)
+    batches = []
+    for b in range(args.steps + args.warmup):
+        s, t, _ = synthetic.make_pairs(P, args.points, seed=2021, first_id=(b * world + rank) * P)
+        batches.append((s.to(dev), t.to(dev)))
+    losses = []
+
+    def step(b):
+        s, t = batches[b]
+        T12 = net(s, t)
+        moved = torch.bmm(s, T12[:, :3, :3].transpose(1, 2)) + T12[:, :3, 3].unsqueeze(1)
+        with torch.no_grad():
+            loss, min_1 = Predict_loss(moved, t)
+        losses.append(float(loss.mean()))
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for w in range(args.warmup):
+        step(w)
+    ops.GEMM_LOG = []
+    sync()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(args.warmup + k)
+    sync()
+    dt = time.perf_counter() - t0
+    log, ops.GEMM_LOG = ops.GEMM_LOG, None
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    g_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in log)
+    g_fl = sum(f for _, _, f in log)
+    out = {
+        "metric": "registration pairs/sec (2048-pt partial pairs)", "value": P * world * args.steps / dt,
+        "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"DCP feature head (random-init weights) + HOUV Predict_loss, {args.points}-pt pairs, "
+                               f"batch {P}/GPU (BASELINE configs[4])", "pairs_per_gpu": P, "points": args.points,
+                   "parallelism": f"dp{world}"},
+        "quality": {"mean_houv_loss_of_dcp_answer": float(np.mean(losses[-args.steps:]))},
+        "roofline": {"kernel": "houv::gemm_f32_kernel (v_mfma_f32_32x32x2_f32)", "bound": "mfma",
+                     "achieved": g_fl / (g_ms * 1e-3) / 1e12, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": g_fl / (g_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, "traffic": None, "launches": len(log),
+                     "avg_launch_ms": g_ms / max(len(log), 1), "kernel_time_share": g_ms * 1e-3 / dt},
+    }
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -121,6 +189,8 @@ def main():
     from houv_amd import solver, synthetic
     from houv_amd.models.houv import HOUV
 
+    if args.dcp:
+        return bench_dcp(args, dev, world, rank)
     P = args.pairs
     n_total = P * world
     # synthetic MVP-shaped pairs, a different slice per rank and per step; resident in HBM before timing starts

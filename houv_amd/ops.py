@@ -219,6 +219,10 @@ def ctypes_ptr(t):
     return ctypes.c_void_p(t.data_ptr())
 
 
+# bench.py sets this to a list to collect (start_event, end_event, flops) per houv_gemm_f32 launch
+GEMM_LOG = None
+
+
 def gemm(A, B, C=None, *, trans_b=True, alpha=1.0, scale=None, shift=None, residual=None, relu=False):
     """2-D or batched (3-/4-D leading dims = (outer[, inner])) fp32 GEMM on the MFMA kernel.
     A[..., M, K]; B[..., N, K] if trans_b else B[..., K, N]; returns C[..., M, N].  Inner-most dims may be strided
@@ -242,6 +246,10 @@ def gemm(A, B, C=None, *, trans_b=True, alpha=1.0, scale=None, shift=None, resid
     ldb, sBo, sBi = strides(B)
     ldc, sCo, sCi = strides(C)
     ldr, sRo, sRi = strides(residual) if residual is not None else (0, 0, 0)
+    if GEMM_LOG is not None:
+        ev0 = torch.cuda.Event(enable_timing=True)
+        ev1 = torch.cuda.Event(enable_timing=True)
+        ev0.record(torch.cuda.current_stream(A.device))
     with torch.cuda.device(A.device):
         ok = _lib.load().houv_gemm_f32(ctypes_ptr(A), ctypes_ptr(B), ctypes_ptr(C), M, N, K, lda, ldb, ldc,
                                        int(bool(trans_b)), outer, inner, sAo, sAi, sBo, sBi, sCo, sCi, float(alpha),
@@ -249,6 +257,9 @@ def gemm(A, B, C=None, *, trans_b=True, alpha=1.0, scale=None, shift=None, resid
                                        None if residual is None else ctypes_ptr(residual), ldr, sRo, sRi,
                                        int(bool(relu)), _lib.stream_of(A))
     _lib.check(ok, "houv_gemm_f32")
+    if GEMM_LOG is not None:
+        ev1.record(torch.cuda.current_stream(A.device))
+        GEMM_LOG.append((ev0, ev1, 2.0 * outer * inner * M * N * K))
     return C
 
 
