@@ -159,3 +159,17 @@ def test_full_size_properties(dev):
     assert torch.equal(e1, d1) and torch.equal(j1, i1) and torch.equal(e2, d2) and torch.equal(j2, i2)
     s1, s2, k1, k2 = cd()(a, a)
     assert float(s1.max()) == 0.0 and torch.equal(k1.cpu().long(), torch.arange(2048).expand(B, -1))
+
+
+def test_torch_ops_registration(dev):
+    """The ops are also reachable as PyTorch-ROCm custom ops: torch.ops.houv.* (in-place outputs declared in the schema)."""
+    from houv_amd import ops
+    ops.register_torch_ops()
+    a = torch.rand(2, 40, 3, device=dev); b = torch.rand(2, 30, 3, device=dev)
+    d1 = torch.empty(2, 40, device=dev); d2 = torch.empty(2, 30, device=dev)
+    i1 = torch.empty(2, 40, dtype=torch.int32, device=dev); i2 = torch.empty(2, 30, dtype=torch.int32, device=dev)
+    assert torch.ops.houv.chamfer_forward(a, b, d1, d2, i1, i2) == 1
+    o1, o2, j1, j2 = orc.chamfer_nn(a.cpu(), b.cpu())
+    assert torch.equal(i1.cpu(), j1) and torch.equal(i2.cpu(), j2)
+    R, t = torch.ops.houv.kabsch(torch.randn(2, 3, 50, device=dev), torch.randn(2, 3, 50, device=dev), None)
+    assert R.shape == (2, 3, 3) and t.shape == (2, 3)
