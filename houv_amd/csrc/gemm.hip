@@ -11,7 +11,7 @@
 //   BT = false: B is [K,N] row-major (P V of attention)                                  -> C = A B
 //   epilogue  : v = alpha*acc; v = v*scale[n] + shift[n] (eval BatchNorm folded) | v += shift[n] (bias);
 //               v += residual[m,n]; v = max(v,0)
-// Tile 128 x BN x 16, 256 threads = 4 waves (2x2), each wave a 64 x BN/2 block of 32x32 MFMA tiles; LDS tiles are
+// Tile 128 x BN x 32, 256 threads = 4 waves (2x2), each wave a 64 x BN/2 block of 32x32 MFMA tiles; LDS tiles are
 // stored k-major so an MFMA operand fetch is a conflict-free ds_read_b32 (lanes 0-31: 32 consecutive rows at k,
 // lanes 32-63: the same rows at k+1); the next k-tile is prefetched into registers while the current one is
 // multiplied.
@@ -34,7 +34,7 @@ struct GemmArgs {
   int relu;
 };
 
-constexpr int BM = 128, BK = 16;
+constexpr int BM = 128, BK = 32;
 
 __device__ __forceinline__ float4 load4_guarded(const float* __restrict__ p, int valid, bool vec_ok) {
   // up to 4 consecutive floats starting at p; `valid` of them exist (0..4)
@@ -52,7 +52,10 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
   constexpr int LDA = BM + 1;                         // k-major tiles, +1 breaks the transposing writes' conflicts
   constexpr int LDB = BT ? (BN + 1) : (BN + 4);       // the [K,N] form is written with 16-byte stores
   constexpr int NI = BN / 64;                         // 32-wide MFMA tiles per wave along N
-  constexpr int BREG = BT ? (BN * BK / 4 / 256) : (BN * BK / 4 / 256);
+  constexpr int AREG = BM * BK / 4 / 256;             // float4 per thread per A tile
+  constexpr int BREG = BN * BK / 4 / 256;
+  constexpr int QK = BK / 4;                          // k-quads per row
+  constexpr int RPI = 256 / QK;                       // rows covered per pass
   __shared__ float As[BK * LDA];
   __shared__ __attribute__((aligned(16))) float Bs[BK * LDB];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -73,21 +76,21 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  float4 ra[2], rb[BREG];
+  float4 ra[AREG], rb[BREG];
   auto fetch = [&](int k0) {
-    // A tile: 128 rows x 16 k = 512 float4; thread t -> row t/4 + 64 i, k-quad (t%4)*4
+    // A tile: 128 rows x BK k; thread t -> row t/QK + RPI i, k-quad (t%QK)*4
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int row = m0 + (tid >> 2) + 64 * i, k = k0 + (tid & 3) * 4;
+    for (int i = 0; i < AREG; ++i) {
+      const int row = m0 + tid / QK + RPI * i, k = k0 + (tid % QK) * 4;
       ra[i] = (row < g.M) ? load4_guarded(A + (size_t)row * g.lda + k, g.K - k, vecA) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     if constexpr (BT) {   // B[n][k]: same pattern as A
 #pragma unroll
       for (int i = 0; i < BREG; ++i) {
-        const int col = n0 + (tid >> 2) + 64 * i, k = k0 + (tid & 3) * 4;
+        const int col = n0 + tid / QK + RPI * i, k = k0 + (tid % QK) * 4;
         rb[i] = (col < g.N) ? load4_guarded(B + (size_t)col * g.ldb + k, g.K - k, vecB) : make_float4(0.f, 0.f, 0.f, 0.f);
       }
-    } else {              // B[k][n]: 16 k-rows x BN cols; thread t -> k = t / (BN/4) + (256/(BN/4)) i, n-quad
+    } else {              // B[k][n]: BK k-rows x BN cols; thread t -> k = t / (BN/4) + (256/(BN/4)) i, n-quad
       constexpr int QPR = BN / 4, RPP = 256 / QPR;
 #pragma unroll
       for (int i = 0; i < BREG; ++i) {
@@ -98,15 +101,15 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
   };
   auto stage = [&]() {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int r = (tid >> 2) + 64 * i, k = (tid & 3) * 4;
+    for (int i = 0; i < AREG; ++i) {
+      const int r = tid / QK + RPI * i, k = (tid % QK) * 4;
       As[(k + 0) * LDA + r] = ra[i].x; As[(k + 1) * LDA + r] = ra[i].y;
       As[(k + 2) * LDA + r] = ra[i].z; As[(k + 3) * LDA + r] = ra[i].w;
     }
     if constexpr (BT) {
 #pragma unroll
       for (int i = 0; i < BREG; ++i) {
-        const int c = (tid >> 2) + 64 * i, k = (tid & 3) * 4;
+        const int c = tid / QK + RPI * i, k = (tid % QK) * 4;
         Bs[(k + 0) * LDB + c] = rb[i].x; Bs[(k + 1) * LDB + c] = rb[i].y;
         Bs[(k + 2) * LDB + c] = rb[i].z; Bs[(k + 3) * LDB + c] = rb[i].w;
       }
@@ -127,17 +130,27 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
     __syncthreads();
     if (k0 + BK < g.K) fetch(k0 + BK);     // prefetch the next tile into registers under the MFMAs
     const int kh = lane >> 5, rl = lane & 31;
+    // operand fragments are double buffered in registers: the ds_reads of k-step s+1 are issued before the MFMAs of
+    // k-step s, so their latency hides under 4 x 64 MFMA cycles even when all waves of a SIMD run in lock-step
+    float a[2][2], b[2][NI];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) a[0][i] = As[kh * LDA + wm * 64 + i * 32 + rl];
+#pragma unroll
+    for (int j = 0; j < NI; ++j) b[0][j] = Bs[kh * LDB + wn * (BN / 2) + j * 32 + rl];
 #pragma unroll
     for (int kk = 0; kk < BK; kk += 2) {
-      float a[2], b[NI];
+      const int cur = (kk >> 1) & 1, nxt = cur ^ 1;
+      if (kk + 2 < BK) {
 #pragma unroll
-      for (int i = 0; i < 2; ++i) a[i] = As[(kk + kh) * LDA + wm * 64 + i * 32 + rl];
+        for (int i = 0; i < 2; ++i) a[nxt][i] = As[(kk + 2 + kh) * LDA + wm * 64 + i * 32 + rl];
 #pragma unroll
-      for (int j = 0; j < NI; ++j) b[j] = Bs[(kk + kh) * LDB + wn * (BN / 2) + j * 32 + rl];
+        for (int j = 0; j < NI; ++j) b[nxt][j] = Bs[(kk + 2 + kh) * LDB + wn * (BN / 2) + j * 32 + rl];
+      }
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < NI; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i], b[cur][j], acc[i][j], 0, 0, 0);
     }
   }
 

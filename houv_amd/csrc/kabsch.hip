@@ -120,11 +120,15 @@ __global__ __launch_bounds__(kKBlock) void kabsch_kernel(const float* __restrict
 extern "C" int houv_kabsch(const float* src, const float* corr, const float* w_or_null, int B, int N, float* R,
                            float* t, void* stream) {
   using namespace houv;
-  if (B < 0 || N <= 0 || !src || !corr || !R || !t) {
+  if (B < 0 || N <= 0) {
     set_error("houv_kabsch: bad argument B=%d N=%d", B, N);
     return 0;
   }
   if (B == 0) return 1;
+  if (!src || !corr || !R || !t) {
+    set_error("houv_kabsch: null pointer");
+    return 0;
+  }
   kabsch_kernel<<<(B + kSamplesPerBlock - 1) / kSamplesPerBlock, kKBlock, 0, (hipStream_t)stream>>>(src, corr, w_or_null, B, N, R, t);
   return check_launch("houv_kabsch") ? 1 : 0;
 }

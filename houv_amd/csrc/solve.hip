@@ -205,7 +205,8 @@ __device__ __forceinline__ void epilogue_metric(const Smem& sm, const float4* __
 #pragma unroll
   for (int k = 0; k < Q; ++k) {
     if (sel[k]) {
-      const float s = sqrtf(bestm[k]);
+      // no finite distance (NaN pose from an earlier sqrt'(0)): torch's min/topk/sqrt chain yields NaN, not inf
+      const float s = (bestm[k] < INFINITY) ? sqrtf(bestm[k]) : NAN;
       const float inv = 1.0f / s;   // d == 0 -> inf, and 0*inf = NaN below, as torch's sqrt backward gives
       float dx, dy, dz, sx, sy, sz;
       if constexpr (DIR == 1) {

@@ -202,3 +202,38 @@ def test_full_size_properties_cfg2_shape(dev):
     out2, _ = solver.run_stage(src, tgt, p0, K, 40, **kw)
     better = (out2["score"].reshape(P, K).min(1)[0] <= out["score"].reshape(P, K).min(1)[0]).float().mean()
     assert float(better) >= 0.75
+
+
+def test_zero_distance_poisons_only_that_hypothesis(dev):
+    """a nearest-neighbour distance of exactly 0 makes sqrt's backward NaN (model_utils_completion.py:94-95),
+    which poisons that hypothesis only; NaN scores lose the best-of-K (topk sorts NaN last)."""
+    from houv_amd import ops, solver, synthetic
+    src, _, _ = synthetic.make_pairs(1, 64, seed=2)
+    src = src.to(dev)
+    K = 26
+    p0 = solver.houv_init_params(K)
+    p0[3, 3] = -0.5      # theta = sin(-pi/2) pi/8 + pi/8 = 0  -> R = I
+    p0[3, 7] = -0.5      # sigma = sin(-pi/2)/8 + 1/8 = 0       -> T = 0: hypothesis 3 moves nothing, every d == 0
+    out1, st = solver.run_stage(src, src.clone(), p0, K, 1, angle_base=0, trans_mode=0, use_views=True, f64_params=False,
+                                lr=0.01, want_grad=True)
+    assert float(out1["score"][3]) == 0.0 and float(out1["loss"][3]) == 0.0
+    assert bool(torch.isnan(out1["grad"][3]).all()) and bool(torch.isnan(st[3, :8]).all())
+    others = torch.arange(K, device=dev) != 3
+    assert bool(torch.isfinite(out1["grad"][others]).all()) and bool(torch.isfinite(st[others]).all())
+    out2, _ = solver.run_stage(src, src.clone(), p0, K, 2, angle_base=0, trans_mode=0, use_views=True, f64_params=False, lr=0.01)
+    assert bool(torch.isnan(out2["score"][3])) and bool(torch.isfinite(out2["score"][others]).all())
+    best, _ = out2["score"].reshape(1, K).topk(1, dim=1, largest=False)
+    assert bool(torch.isfinite(best).all())
+
+
+def test_empty_batches_are_no_ops(dev):
+    from houv_amd import ops
+    e = torch.zeros((0, 8, 3), device=dev)
+    st = torch.zeros((0, 24), dtype=torch.float64, device=dev)
+    out = ops.solve_iterate(e, e, st, 4, steps_done=0, n_iters=1, angle_base=0, trans_mode=0, use_views=True,
+                            f64_params=False, k_full=4, k_view=8, lr=0.01, loss_scale=1.0)
+    assert out["score"].numel() == 0
+    d1 = torch.zeros((0, 8), device=dev); i1 = torch.zeros((0, 8), dtype=torch.int32, device=dev)
+    assert ops.chamfer_forward(e, e, d1, d1.clone(), i1, i1.clone()) == 1
+    R, t = ops.kabsch(torch.zeros((0, 3, 5), device=dev), torch.zeros((0, 3, 5), device=dev))
+    assert R.shape == (0, 3, 3)
