@@ -37,6 +37,9 @@ _SIGNATURES = {
     "houv_layernorm": (ctypes.c_int, [_c_f, ctypes.c_longlong, _int, _c_f, _c_f, _flt, _c_f, _c_f, _c_f]),
     "houv_softmax_rows": (ctypes.c_int, [_c_f, ctypes.c_longlong, _int, _c_f]),
     "houv_softmax_corr": (ctypes.c_int, [_c_f, _int, _int, _int, _c_f, _c_f, _c_f]),
+    "houv_furthest_point_sample": (ctypes.c_int, [_c_f, _int, _int, _int, _c_f, _c_f]),
+    "houv_knn_cross": (ctypes.c_int, [_c_f, _c_f, _int, _int, _int, _int, _c_f, _c_f, _c_f]),
+    "houv_gather_points": (ctypes.c_int, [_c_f, _c_f, _int, _int, _int, _int, _c_f, _c_f]),
     "houv_pose_forward": (ctypes.c_int, [_c_f, _int, _int, _int, _c_f, _int, _c_f, _c_f, _c_f, _c_f]),
 }
 

@@ -93,3 +93,13 @@ def solve(src, src_rotated, pose=None, src_ori=None, tgt_ori=None, angle_t=None,
     t_err = translation_error(ans[:, :3, 3], pose[:, :3, 3])
     print(r_err.mean(), t_err.mean(), score.min(dim=1)[0].max())
     return r_err, t_err, ans
+
+
+def combine(src, tgt):
+    """train_utils.py:459-464: concatenate both clouds and furthest-point-sample 2048 of them.  (The reference hands the
+    [B,3,2N] transposed tensor to an op that expects [B,N,3]; the evident intent -- sampling points -- is what this does.)"""
+    from .mm3d_pn2 import furthest_point_sample, gather_points
+    pts = torch.cat([src, tgt], dim=1).contiguous()                   # [B, 2N, 3]
+    data = pts.transpose(1, 2).contiguous()                           # [B, 3, 2N]
+    sample_idx = furthest_point_sample(pts, 2048)
+    return gather_points(data, sample_idx).transpose(1, 2).contiguous()

@@ -146,6 +146,22 @@ int houv_softmax_rows(float* x, long long rows, int L, void* stream);
 /* dcp.py:346-348: corr[P,3,N] = pts[P,M,3]^T . softmax(scores[P,N,M])^T, one pass per score row. */
 int houv_softmax_corr(const float* scores, int P, int N, int M, const float* pts, float* corr, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Sibling point ops of utils/mm3d_pn2 (call site registration/train_utils.py:459-464 `combine`).
+ * The reference's CUDA extensions cannot run here and it holds no fixtures for them: parity unpinned. */
+
+/* furthest_point_sample (utils/mm3d_pn2/ops/furthest_point_sample/furthest_point_sample.py:15-36): idx[B,npoint],
+ * starting from point 0, each next sample = the point furthest from the chosen set (lowest index on ties). */
+int houv_furthest_point_sample(const float* xyz, int B, int N, int npoint, int32_t* idx, void* stream);
+
+/* three_nn generalised (utils/mm3d_pn2/ops/interpolate/three_nn.py:11-37): the k (1, 3 or 8) nearest points of ref[B,M,3]
+ * for every query[B,N,3], nearest first: dist2[B,N,k] SQUARED distances, idx[B,N,k]. */
+int houv_knn_cross(const float* query, const float* ref, int B, int N, int M, int k, float* dist2, int32_t* idx,
+                   void* stream);
+
+/* gather_points (utils/mm3d_pn2/ops/gather_points/gather_points.py:14-35): out[B,C,M] = features[B,C,idx[B,M]]. */
+int houv_gather_points(const float* features, const int32_t* idx, int B, int C, int N, int M, float* out, void* stream);
+
 /* Pose only (HOUV.forward, houv.py:94-103): params fp32 [n,8] -> R[n,9], T[n,3]; if src != NULL
  * also moved[n,N,3] = src[n,N,3] @ R^T + T. */
 int houv_pose_forward(const float* params, int n, int angle_base, int trans_mode,
