@@ -6,6 +6,8 @@ The reference's drivers do (registration/train_HOUV.py:26-38, model_utils_comple
     from models.houv import HOUV, predict_model, solve_model
     from train_utils import solve, rotation_error, translation_error, rmse_loss, AverageValueMeter
     from model_utils import SVDHead
+    from models.dcp import Model                      # registration/models/dcp.py (inference)
+    from mm3d_pn2 import furthest_point_sample, gather_points
 
 After ``houv_amd.compat.install()`` those statements import the MI355X implementations."""
 import importlib
@@ -15,6 +17,8 @@ _ALIASES = {
     "metrics": "houv_amd.metrics",
     "models": "houv_amd.models",
     "models.houv": "houv_amd.models.houv",
+    "models.dcp": "houv_amd.models.dcp",
+    "mm3d_pn2": "houv_amd.mm3d_pn2",
     "train_utils": "houv_amd.train_utils",
     "model_utils": "houv_amd.model_utils",
     "model_utils_completion": "houv_amd.model_utils_completion",

@@ -26,8 +26,8 @@ def test_config_accepts_reference_yaml_surface(tmp_path):
 
 def test_compat_aliases_resolve_reference_imports():
     from houv_amd import compat
-    saved = {k: sys.modules.get(k) for k in ("metrics", "models", "models.houv", "train_utils", "model_utils",
-                                             "model_utils_completion")}
+    saved = {k: sys.modules.get(k) for k in ("metrics", "models", "models.houv", "models.dcp", "mm3d_pn2", "train_utils",
+                                             "model_utils", "model_utils_completion")}
     for k in saved:
         sys.modules.pop(k, None)
     try:
@@ -37,6 +37,8 @@ def test_compat_aliases_resolve_reference_imports():
         from train_utils import (AverageValueMeter, rmse_loss, rotation_error, solve,   # noqa: F401
                                  translation_error)
         from model_utils import SVDHead                                            # noqa: F401
+        from models.dcp import Model                                               # noqa: F401
+        from mm3d_pn2 import furthest_point_sample, gather_points                  # noqa: F401
         import houv_amd.models.houv as mine
         assert predict_model is mine.predict_model
     finally:
