@@ -8,7 +8,7 @@ A "step" is one full `solve_model` pass (registration/models/houv.py:142-206: ba
 Adam iterations, then the data-dependent retry stages at bases 1..3) over one batch of synthetic MVP-shaped pairs
 resident in HBM.  N=1 workload = BASELINE.json configs[1]: 2048x2048-point pairs, batch 256.  For N>1 every rank
 solves its own batch of the same size (weak scaling; pairs are independent, no data-path collective) and the ranks
-exchange the per-pair (R,t) with ONE RCCL all-gather per step.  Rank 0 prints one JSON line.
+exchange the per-pair (R,t) of all timed steps with ONE RCCL all-gather inside the timed region.  Rank 0 prints one JSON line.
 
 Extra objects on the line:
   roofline      the dominant kernel (houv::solve_kernel), timed live with HIP events on its launch stream
@@ -218,11 +218,18 @@ def main():
             from houv_amd.icp import icp_refine
             ans = icp_refine(s, t, ans)
             ans[:, 3, :] = 0.0                                               # keep the results layout of houv.py:187-195
-        if world > 1:                                                        # ONE all-gather of [P,12] per rank
-            full = hd.gather_transforms(ans if args.backend == "nccl" else ans.cpu(), n_total).to(dev)
-        else:
-            full = ans
-        results.append((b, full))
+        results.append((b, ans))
+
+    def gather_all():
+        """The path's single collective (north_star: "a single RCCL all-gather of per-pair (R,t)"): every rank's
+        transforms of ALL its steps in one [steps*P, 12] all-gather -- no per-step synchronisation between ranks,
+        exactly like the reference, whose shards only meet in the final --combine (run_test.sh:21-23)."""
+        if world == 1:
+            return [a for _, a in results]
+        mine = torch.cat([a for _, a in results], 0)
+        full = hd.gather_transforms(mine if args.backend == "nccl" else mine.cpu(), mine.shape[0] * world).to(dev)
+        per_rank = full.reshape(world, len(results), P, 4, 4)
+        return [per_rank[:, i].reshape(world * P, 4, 4) for i in range(len(results))]
 
     def sync():
         if world > 1:
@@ -232,12 +239,14 @@ def main():
     solver.LAUNCH_LOG = []
     for w in range(args.warmup):
         step(w)
+    gather_all()
     results.clear()
     n_warm_launches = len(solver.LAUNCH_LOG)
     sync()
     t0 = time.perf_counter()
     for k in range(args.steps):
         step(args.warmup + k)
+    gathered = gather_all()
     sync()
     dt = time.perf_counter() - t0
     log_all, solver.LAUNCH_LOG = solver.LAUNCH_LOG, None
@@ -249,7 +258,8 @@ def main():
 
     # ---- accuracy of what was just timed (sanity, rank-local batch of the last step) ----
     from houv_amd.train_utils import rotation_error, translation_error
-    b_last, full = results[-1]
+    b_last = results[-1][0]
+    full = gathered[-1]
     pose = batches[b_last][2]
     mine = full[rank * P:(rank + 1) * P] if world > 1 else full
     r_err = rotation_error(mine[:, :3, :3], pose[:, :3, :3])
@@ -292,7 +302,7 @@ def main():
                    "pairs_per_gpu": P, "points": args.points, "kernel": args.kernel, "iters": args.iters,
                    "icp_refine": bool(args.icp),
                    "parallelism": f"dp{world} (pair shards, one {'RCCL' if args.backend == 'nccl' else 'gloo'} "
-                                  "all-gather of [P,12] per step)"},
+                                  "all-gather of [steps*P,12] per rank)"},
         "quality": {"mean_rot_err_deg": float(r_err.mean()), "median_rot_err_deg": float(r_err.median()),
                     "mean_trans_err": float(t_err.mean()),
                     "hypothesis_iterations_per_pair": inst_iters / (P * args.steps)},
