@@ -237,3 +237,40 @@ def test_empty_batches_are_no_ops(dev):
     assert ops.chamfer_forward(e, e, d1, d1.clone(), i1, i1.clone()) == 1
     R, t = ops.kabsch(torch.zeros((0, 3, 5), device=dev), torch.zeros((0, 3, 5), device=dev))
     assert R.shape == (0, 3, 3)
+
+
+def test_unfused_loss_glue_vs_golden(golden, dev):
+    """a8-a10 through the un-fused mirrors (metrics.cd autograd + torch.topk): calc_cd_percent, loss_view, Predict_loss
+    values and the gradient w.r.t. the moved cloud against the reference's own numbers (G2)."""
+    from houv_amd.model_utils_completion import calc_cd_percent, loss_view
+    from houv_amd.models.houv import Predict_loss
+    g = golden("g2_loss.npz")
+    mv = T(g["moved"]).to(dev).requires_grad_(True)
+    tg = T(g["target"]).to(dev)
+    c = calc_cd_percent(mv, tg, percent=0.5)
+    np.testing.assert_allclose(np.stack([x.detach().cpu().numpy() for x in c]), g["cd_percent"], atol=1e-6)
+    for d in range(3):
+        v = loss_view(mv, tg, dim=d)
+        np.testing.assert_allclose(np.stack([x.detach().cpu().numpy() for x in v]), g["views"][d], atol=1e-6)
+    loss, min1 = Predict_loss(mv, tg)
+    loss.mean().backward()
+    np.testing.assert_allclose(loss.detach().cpu().numpy(), g["loss"], atol=5e-6)
+    np.testing.assert_allclose(min1.detach().cpu().numpy(), g["min_1"], atol=1e-6)
+    gm = mv.grad.cpu().numpy()
+    np.testing.assert_allclose(gm, g["grad_moved"], atol=1e-6 * max(1.0, np.abs(g["grad_moved"]).max() * 1e3), rtol=2e-3)
+
+
+def test_solve_twin_end_to_end_vs_oracle(golden, dev):
+    """a15 end to end (`solve`: base stage + retry stages, float64 leaves from the harness-seeded global numpy RNG,
+    lr 0.1) at a shortened horizon (_iters=12; the reference hard-codes 500): same retry decisions and transforms as the
+    oracle, to the looseness lr=0.1 imposes after a dozen steps."""
+    from houv_amd.train_utils import solve
+    g = golden("g6_solve.npz")
+    s, t = T(g["solve_src"]), T(g["solve_tgt"])
+    np.random.seed(123)
+    ref = orc.solve(s, t, kernel=13, prefix="test", _iters=12)
+    np.random.seed(123)
+    mine = solve(s.to(dev), t.to(dev), kernel=13, prefix="test", _iters=12)
+    assert not mine.is_cuda and mine.shape == ref.shape
+    np.testing.assert_allclose(mine.numpy(), ref.numpy(), atol=2e-2)
+    assert np.all(mine.numpy()[:, 3, :] == 0)
