@@ -151,6 +151,10 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
 #pragma unroll
         for (int j = 0; j < NI; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i], b[cur][j], acc[i][j], 0, 0, 0);
+      // pin the schedule hipcc would otherwise undo (it sinks the next step's LDS reads below these MFMAs and then waits
+      // for them with the matrix pipe idle): first the DS reads of step s+1, then the MFMAs of step s
+      __builtin_amdgcn_sched_group_barrier(0x100, 2 + NI, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 2 * NI, 0);
     }
   }
 
