@@ -30,11 +30,16 @@ def save_results(log_dir, results):
     os.makedirs(log_dir, exist_ok=True)
     arr = np.asarray(results, dtype=np.float32)
     np.save(os.path.join(log_dir, "results.npy"), arr)
+    out = os.path.join(log_dir, "results.npy")
     if h5py is not None:
-        with h5py.File(os.path.join(log_dir, "results.h5"), "w") as f:
+        out = os.path.join(log_dir, "results.h5")
+        with h5py.File(out, "w") as f:
             f.create_dataset("results", data=arr)
-        return os.path.join(log_dir, "results.h5")
-    return os.path.join(log_dir, "results.npy")
+    # test.py:73-76 shells out to `zip -r submission.zip results.h5`; same archive, without the subprocess
+    import zipfile
+    with zipfile.ZipFile(os.path.join(log_dir, "submission.zip"), "w", zipfile.ZIP_DEFLATED) as z:
+        z.write(out, os.path.basename(out))
+    return out
 
 
 def load_mvp_rg(path, l=None, r=None):

@@ -110,6 +110,9 @@ def test_shard_files_and_combine(tmp_path):
     np.testing.assert_array_equal(res, np.concatenate(parts, 0))
     out = hio.save_results(str(tmp_path), res)
     assert os.path.exists(out)
+    import zipfile
+    with zipfile.ZipFile(os.path.join(str(tmp_path), "submission.zip")) as z:          # test.py:73-76
+        assert z.namelist() == [os.path.basename(out)]
     np.testing.assert_array_equal(np.load(os.path.join(str(tmp_path), "results.npy")), res)
 
 
@@ -122,3 +125,21 @@ def test_synthetic_pairs_are_mvp_shaped():
     assert float(T[:, :3, 3].norm(dim=1).max()) <= 0.25 + 1e-6          # random_translation(0.25)
     s2, _, _ = synthetic.make_pairs(5, 256, seed=1)
     assert torch.equal(s, s2)                                            # deterministic per (seed, pair id)
+
+
+def test_dataset_layouts_and_pose_samplers():
+    from houv_amd import dataset
+    from houv_amd.config import Config
+    args = Config(num_points=64, manual_seed=3)
+    val = dataset.SyntheticRG("val", args, n_pairs=3)
+    item = val[1]
+    assert len(item) == 17 and item[2].shape == (64, 3) and item[4].shape == (4, 4)        # dataset.py:346
+    test = dataset.SyntheticRG("test", args, n_pairs=3)
+    assert len(test[0]) == 3 and len(test) == 3                                            # dataset.py:348
+    np.random.seed(0)
+    P, ang = dataset.random_pose(np.pi / 4, 0.25)
+    assert P.shape == (4, 4) and 0 <= ang <= np.pi / 4 and np.linalg.norm(P[:3, 3]) <= 0.25 + 1e-12
+    np.testing.assert_allclose(P[:3, :3] @ P[:3, :3].T, np.eye(3), atol=1e-12)
+    assert abs(dataset.rotation_angle_deg(P[:3, :3]) - np.degrees(ang)) < 1e-6
+    with pytest.raises(RuntimeError):
+        dataset.MVP_RG_rotated("test", args)                 # no h5py / no MVP files here: a clear error, not a crash
