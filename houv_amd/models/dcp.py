@@ -182,6 +182,34 @@ class DGCNN(nn.Module):
         return emb.view(P, N, 512)
 
 
+class _Conv1d1x1(nn.Module):
+    def __init__(self, n_in, n_out):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(n_out, n_in, 1).uniform_(-1, 1) / math.sqrt(n_in))
+
+
+class PointNet(nn.Module):
+    """The per-point MLP embedding of dcp.py:246-266 (3->64->64->64->128->512, BatchNorm1d + ReLU after each 1x1 conv):
+    five MFMA GEMMs with the folded-BN/ReLU epilogue.  `Model` uses DGCNN, like the reference (:388)."""
+
+    def __init__(self, emb_dims=512):
+        super().__init__()
+        dims = (3, 64, 64, 64, 128, emb_dims)
+        for i in range(5):
+            setattr(self, f"conv{i + 1}", _Conv1d1x1(dims[i], dims[i + 1]))
+            setattr(self, f"bn{i + 1}", _BN(dims[i + 1]))
+
+    def forward(self, xyz):
+        """xyz[P,N,3] -> [P,N,512] token-major (the reference takes [P,3,N] and returns [P,512,N])."""
+        P, N, _ = xyz.shape
+        x = xyz.reshape(P * N, 3).contiguous()
+        for i in range(1, 6):
+            conv, bn = getattr(self, f"conv{i}"), getattr(self, f"bn{i}")
+            s, h = bn.folded()
+            x = ops.gemm(x, conv.weight.reshape(conv.weight.shape[0], conv.weight.shape[1]), scale=s, shift=h, relu=True)
+        return x.view(P, N, -1)
+
+
 class SVDHead(nn.Module):
     def __init__(self, args=None):
         super().__init__()

@@ -50,3 +50,17 @@ def make_state(seed=1234):
             v = rng.uniform(-1, 1, shape) / np.sqrt(fan_in)
         st[name] = v.astype(np.float32)
     return st
+
+
+def make_pointnet_state(seed=99):
+    """Seeded weights for dcp.py's PointNet embedding (:246-258)."""
+    rng = np.random.default_rng(seed)
+    dims = (3, 64, 64, 64, 128, 512)
+    st = {}
+    for i in range(5):
+        st[f"conv{i + 1}.weight"] = (rng.uniform(-1, 1, (dims[i + 1], dims[i], 1)) / np.sqrt(dims[i])).astype(np.float32)
+        st[f"bn{i + 1}.weight"] = rng.uniform(0.5, 1.5, dims[i + 1]).astype(np.float32)
+        st[f"bn{i + 1}.bias"] = rng.normal(0, 0.2, dims[i + 1]).astype(np.float32)
+        st[f"bn{i + 1}.running_mean"] = rng.normal(0, 0.2, dims[i + 1]).astype(np.float32)
+        st[f"bn{i + 1}.running_var"] = rng.uniform(0.5, 1.5, dims[i + 1]).astype(np.float32)
+    return st

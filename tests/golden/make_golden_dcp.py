@@ -56,6 +56,13 @@ def main():
                         f"{name}_ptr_tgt": pt.numpy()})
         else:                    # a strided sample of the embeddings at the larger size
             out.update({f"{name}_emb_src_s": es.numpy()[:, ::8, ::8], f"{name}_ptr_tgt_s": pt.numpy()[:, ::8, ::8]})
+    # PointNet embedding (dcp.py:246-266) with its own seeded weights
+    pn = dcp.PointNet(512)
+    pstate = dcp_weights.make_pointnet_state(99)
+    pn.load_state_dict({k: torch.tensor(v) for k, v in pstate.items()}, strict=False)
+    pn.eval()
+    with torch.no_grad():
+        out["pointnet_emb"] = pn(torch.tensor(out["small_src"]).transpose(1, 2).contiguous()).numpy()
     np.savez_compressed(f"{OUT}/g9_dcp.npz", **out)
     print("wrote g9_dcp.npz (weights are regenerated from tests/golden/dcp_weights.py, seed 1234)")
 

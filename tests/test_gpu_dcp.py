@@ -144,3 +144,13 @@ def test_model_with_T_gt_returns_reference_tuple(dev):
     src, tgt, pose = synthetic.make_pairs(3, 128, seed=8)
     out = net(src.to(dev), tgt.to(dev), pose.to(dev))
     assert len(out) == 5 and out[1].shape == (3,) and out[0].ndim == 0
+
+
+def test_pointnet_embedding_vs_reference_golden(golden, dev):
+    from houv_amd.models.dcp import PointNet
+    g = golden("g9_dcp.npz")
+    pn = PointNet(512)
+    missing, unexpected = pn.load_state_dict({k: T(v) for k, v in dcp_weights.make_pointnet_state(99).items()}, strict=False)
+    assert not unexpected and all(m.endswith("num_batches_tracked") for m in missing)
+    emb = pn.to(dev)(T(g["small_src"]).to(dev))
+    np.testing.assert_allclose(emb.transpose(1, 2).cpu().numpy(), g["pointnet_emb"], atol=2e-4, rtol=1e-4)
