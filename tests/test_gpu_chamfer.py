@@ -173,3 +173,31 @@ def test_torch_ops_registration(dev):
     assert torch.equal(i1.cpu(), j1) and torch.equal(i2.cpu(), j2)
     R, t = torch.ops.houv.kabsch(torch.randn(2, 3, 50, device=dev), torch.randn(2, 3, 50, device=dev), None)
     assert R.shape == (2, 3, 3) and t.shape == (2, 3)
+
+
+def test_property_based_bit_exact_vs_c_oracle(dev):
+    """Randomised shapes / value ranges / duplicate patterns (hypothesis, 30 examples): HIP op == C oracle bit for bit."""
+    from hypothesis import given, settings, strategies as st, HealthCheck
+    from oracle import c_oracle
+    from houv_amd.metrics import cd
+
+    @settings(max_examples=30, deadline=None, suppress_health_check=list(HealthCheck))
+    @given(B=st.integers(1, 4), N=st.integers(1, 700), M=st.integers(1, 2300), seed=st.integers(0, 2 ** 31 - 1),
+           scale=st.sampled_from([1e-3, 1.0, 37.5]), quant=st.sampled_from([0, 4, 64]), dup=st.booleans())
+    def run(B, N, M, seed, scale, quant, dup):
+        rng = np.random.default_rng(seed)
+        a = (rng.random((B, N, 3)) - 0.5) * scale
+        b = (rng.random((B, M, 3)) - 0.5) * scale
+        if quant:                                   # coarse lattice -> many exact ties
+            a = np.round(a / scale * quant) / quant * scale
+            b = np.round(b / scale * quant) / quant * scale
+        if dup and M > 3:
+            b[:, rng.integers(0, M, M // 3)] = b[:, rng.integers(0, M, M // 3)]
+        a = a.astype(np.float32); b = b.astype(np.float32)
+        d1, d2, i1, i2 = cd()(torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev))
+        o1, o2, j1, j2 = c_oracle.chamfer_forward(a, b)
+        assert np.array_equal(d1.cpu().numpy().view(np.uint32), o1.view(np.uint32))
+        assert np.array_equal(d2.cpu().numpy().view(np.uint32), o2.view(np.uint32))
+        assert np.array_equal(i1.cpu().numpy(), j1) and np.array_equal(i2.cpu().numpy(), j2)
+
+    run()
