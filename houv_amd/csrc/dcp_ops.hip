@@ -143,12 +143,40 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
   }
 }
 
-// One wave per row, in place: x = softmax(x) over L columns.
+// One wave per row, in place: x = softmax(x) over L columns.  Rows of up to 4096 floats (multiple of 4, 16-byte aligned)
+// are held in registers -- one 16-byte read and one 16-byte write per element; longer/odd rows take the 3-pass path.
 __global__ __launch_bounds__(256) void softmax_rows_kernel(float* __restrict__ x, size_t rows, int L) {
   const int lane = threadIdx.x & 63;
   const size_t row = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
   float* xr = x + row * L;
+  if ((L & 3) == 0 && L <= 4096 && (reinterpret_cast<uintptr_t>(xr) & 15) == 0) {
+    constexpr int MAXV = 16;                       // 16 float4 per lane x 64 lanes = 4096 floats
+    const int n4 = L >> 2;
+    float4 v[MAXV];
+    float m = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      const int c = lane + 64 * i;
+      v[i] = (c < n4) ? reinterpret_cast<const float4*>(xr)[c] : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+      m = fmaxf(fmaxf(fmaxf(m, v[i].x), fmaxf(v[i].y, v[i].z)), v[i].w);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      v[i].x = expf(v[i].x - m); v[i].y = expf(v[i].y - m); v[i].z = expf(v[i].z - m); v[i].w = expf(v[i].w - m);
+      s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+    const float inv = 1.0f / wave_sum(s);
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      const int c = lane + 64 * i;
+      if (c < n4) reinterpret_cast<float4*>(xr)[c] = make_float4(v[i].x * inv, v[i].y * inv, v[i].z * inv, v[i].w * inv);
+    }
+    return;
+  }
   float m = -INFINITY;
   for (int i = lane; i < L; i += 64) m = fmaxf(m, xr[i]);
 #pragma unroll
