@@ -201,3 +201,17 @@ def test_property_based_bit_exact_vs_c_oracle(dev):
         assert np.array_equal(i1.cpu().numpy(), j1) and np.array_equal(i2.cpu().numpy(), j2)
 
     run()
+
+
+@pytest.mark.parametrize("N,M", [(700, 900), (7000, 6500)])      # LDS-accumulator path / global-atomics fallback path
+def test_backward_both_paths_vs_closed_form(dev, N, M):
+    from houv_amd.metrics import cd
+    gen = torch.Generator().manual_seed(N)
+    a = torch.rand(1, N, 3, generator=gen); b = torch.rand(1, M, 3, generator=gen)
+    w1 = torch.rand(1, N, generator=gen); w2 = torch.rand(1, M, generator=gen)
+    ag = a.to(dev).requires_grad_(True); bg = b.to(dev).requires_grad_(True)
+    d1, d2, i1, i2 = cd()(ag, bg)
+    ((d1 * w1.to(dev)).sum() + (d2 * w2.to(dev)).sum()).backward()
+    gx1, gx2 = orc.chamfer_backward_closed_form(a, b, i1.cpu(), i2.cpu(), w1, w2)
+    np.testing.assert_allclose(ag.grad.cpu().numpy(), gx1.numpy(), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(bg.grad.cpu().numpy(), gx2.numpy(), rtol=1e-4, atol=1e-5)
