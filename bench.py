@@ -224,7 +224,7 @@ def main():
         """The path's single collective (north_star: "a single RCCL all-gather of per-pair (R,t)"): every rank's
         transforms of ALL its steps in one [steps*P, 12] all-gather -- no per-step synchronisation between ranks,
         exactly like the reference, whose shards only meet in the final --combine (run_test.sh:21-23)."""
-        if world == 1:
+        if world == 1 or not results:
             return [a for _, a in results]
         mine = torch.cat([a for _, a in results], 0)
         full = hd.gather_transforms(mine if args.backend == "nccl" else mine.cpu(), mine.shape[0] * world).to(dev)
