@@ -48,6 +48,9 @@ def parse():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (default); gloo = CPU rehearsal of the N>1 control path")
     ap.add_argument("--single-device", action="store_true", help="rehearsal only: every rank uses cuda:0")
+    ap.add_argument("--solver", default="brute", choices=["brute", "pruned"],
+                    help="brute = the brute-force sweep north_star specifies (default, what the roofline is defined on); "
+                         "pruned = opt-in exact search (bit-identical outputs on the same clouds, Morton-sorted inputs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-chamfer-op", action="store_true")
     return ap.parse_args()
@@ -193,6 +196,7 @@ def main():
         return bench_dcp(args, dev, world, rank)
     P = args.pairs
     n_total = P * world
+    solver.PRUNED = args.solver == "pruned"
     # synthetic MVP-shaped pairs, a different slice per rank and per step; resident in HBM before timing starts
     n_batches = args.steps + args.warmup
     batches = []
@@ -272,7 +276,7 @@ def main():
     flops = evals * FLOP_PER_EVAL
     achieved = flops / (k_ms * 1e-3) / 1e12
     roofline = {
-        "kernel": "houv::solve_kernel<512,4,4>", "bound": "mfma",
+        "kernel": "houv::solve_kernel<512,4,4,%s>" % ("true" if args.solver == "pruned" else "false"), "bound": "mfma",
         "bound_note": "compute bound on the fp32 VALU issue rate; the kernel issues no MFMA -- `peak` is MI355X's dense "
                       "fp32 rate, which is the same 157.3 TFLOP/s for the vector ALUs and for fp32-input MFMA",
         "achieved": achieved, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP32_PEAK_TFLOPS,
@@ -300,7 +304,7 @@ def main():
                                f"K={args.kernel} restarts x {args.iters} Adam iterations + retry stages "
                                "(BASELINE configs[1])",
                    "pairs_per_gpu": P, "points": args.points, "kernel": args.kernel, "iters": args.iters,
-                   "icp_refine": bool(args.icp),
+                   "icp_refine": bool(args.icp), "solver": args.solver,
                    "parallelism": f"dp{world} (pair shards, one {'RCCL' if args.backend == 'nccl' else 'gloo'} "
                                   "all-gather of [steps*P,12] per rank)"},
         "quality": {"mean_rot_err_deg": float(r_err.mean()), "median_rot_err_deg": float(r_err.median()),

@@ -27,6 +27,9 @@ _SIGNATURES = {
     "houv_solve_iterate": (ctypes.c_int, [_c_f, _c_f, _int, _int, _int, _int, _c_f, _int, _int, _int, _int, _int, _int,
                                           _int, _int, _dbl, _dbl, _dbl, _dbl, _flt, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f,
                                           _c_f]),
+    "houv_solve_iterate_pruned": (ctypes.c_int, [_c_f, _c_f, _int, _int, _int, _int, _c_f, _int, _int, _int, _int, _int,
+                                                 _int, _int, _int, _dbl, _dbl, _dbl, _dbl, _flt, _c_f, _c_f, _c_f, _c_f,
+                                                 _c_f, _c_f, _c_f, _int, _int, _c_f]),
     "houv_icp_refine": (ctypes.c_int, [_c_f, _c_f, _int, _int, _int, _c_f, _flt, _int, _flt, _flt, _c_f, _c_f, _c_f, _c_f, _c_f]),
     "houv_knn": (ctypes.c_int, [_c_f, _int, _int, _int, _c_f, _c_f]),
     "houv_edgeconv1": (ctypes.c_int, [_c_f, _c_f, _int, _int, _int, _c_f, _c_f, _c_f, _c_f, _c_f]),

@@ -102,7 +102,8 @@ __global__ __launch_bounds__(BLOCK) void icp_kernel(IcpArgs a) {
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int k = 0; k < Q; ++k) {
-      const float4 nn = recover_nn<0, 4>(s_tgt + btile[k][0] * kSub, px[k], py[k], pz[k], best[k][0], rot);
+      int jn;
+      const float4 nn = recover_nn<0, 4>(s_tgt + btile[k][0] * kSub, px[k], py[k], pz[k], best[k][0], rot, jn);
       nx[k] = nn.x; ny[k] = nn.y; nz[k] = nn.z;
       in[k] = ((k * BLOCK + tid) < N) && (best[k][0] < a.max_dist2);
       if (in[k]) {

@@ -41,6 +41,9 @@ struct SolveArgs {
   float* out_T;
   float* out_grad;
   float* out_cd;
+  short* nn_ws;      // pruned mode: [P*K][2 dirs][4 metrics][ws_stride] index of each query's NN in the last iteration
+  int ws_valid;      //   1: nn_ws holds the NNs of the iteration before this launch's first one
+  int ws_stride;
 };
 
 #ifdef HOUV_STAMPS
@@ -75,13 +78,15 @@ struct Smem {
   float* red;      // [NW][kAccStride]
   unsigned* hist;  // [256]
   int* ctl;        // [8 + NW]
+  float4* tbox;    // [2*64] lo/hi boxes of the target's 32-point sub-tiles   (pruned mode)
+  float4* mbox;    // [2*64] same for the moved cloud, rebuilt every iteration
 };
 
 __host__ __device__ inline size_t smem_bytes(int N, int M, int block) {
   const int npad = (N + kSub - 1) / kSub * kSub, mpad = (M + kSub - 1) / kSub * kSub;
   const int nw = block / 64;
   return (size_t)(npad + mpad) * 16 + 24 * 8 + 12 * 4 + 8 * kAccStride * 4 + (size_t)nw * kAccStride * 4 + 256 * 4 +
-         (8 + nw) * 4 + 64;
+         (8 + nw) * 4 + 64 + 2 * 128 * 16;
 }
 
 __device__ inline Smem carve(unsigned char* base, int N, int M, int block) {
@@ -96,6 +101,8 @@ __device__ inline Smem carve(unsigned char* base, int N, int M, int block) {
   s.red = s.acc + 8 * kAccStride;
   s.hist = reinterpret_cast<unsigned*>(s.red + nw * kAccStride);
   s.ctl = reinterpret_cast<int*>(s.hist + 256);
+  s.tbox = reinterpret_cast<float4*>((reinterpret_cast<uintptr_t>(s.ctl + 8 + nw) + 15) & ~(uintptr_t)15);
+  s.mbox = s.tbox + 128;
   return s;
 }
 
@@ -173,7 +180,7 @@ template <int BLOCK, int Q, int MET, int DIR>
 __device__ __forceinline__ void epilogue_metric(const Smem& sm, const float4* __restrict__ refs, const float (&qx)[Q],
                                                 const float (&qy)[Q], const float (&qz)[Q], const float (&bestm)[Q],
                                                 const int (&btilem)[Q], int count, int ksel, const float (&px)[Q],
-                                                const float (&py)[Q], const float (&pz)[Q], float* acc_out HOUV_STAMP_PARAM) {
+                                                const float (&py)[Q], const float (&pz)[Q], float* acc_out, short* ws HOUV_STAMP_PARAM) {
   const int tid = threadIdx.x;
   const int rot = tid & (kSub - 1);
   float nx[Q], ny[Q], nz[Q];
@@ -182,7 +189,9 @@ __device__ __forceinline__ void epilogue_metric(const Smem& sm, const float4* __
 #pragma unroll
   for (int k = 0; k < Q; ++k) {
     const float bd = bestm[k];
-    const float4 nn = recover_nn<MET, kRescanBatch>(refs + btilem[k] * kSub, qx[k], qy[k], qz[k], bd, rot);
+    int jn;
+    const float4 nn = recover_nn<MET, kRescanBatch>(refs + btilem[k] * kSub, qx[k], qy[k], qz[k], bd, rot, jn);
+    if (ws && (k * BLOCK + tid) < count) ws[k * BLOCK + tid] = (short)(btilem[k] * kSub + jn);
     nx[k] = nn.x; ny[k] = nn.y; nz[k] = nn.z;
     const bool valid = (k * BLOCK + tid) < count;
     key[k] = valid ? __float_as_uint(bd) : 0xFFFFFFFFu;
@@ -239,7 +248,8 @@ template <int BLOCK, int Q, int NMET, int DIR>
 __device__ __forceinline__ void epilogue(const Smem& sm, const float4* __restrict__ refs, const float (&qx)[Q],
                                          const float (&qy)[Q], const float (&qz)[Q], const float (&best)[Q][NMET],
                                          const int (&btile)[Q][NMET], int count, int k_full, int k_view,
-                                         const float (&px)[Q], const float (&py)[Q], const float (&pz)[Q] HOUV_STAMP_PARAM) {
+                                         const float (&px)[Q], const float (&py)[Q], const float (&pz)[Q], short* ws,
+                                         int ws_stride HOUV_STAMP_PARAM) {
   float bm[Q];
   int bt[Q];
 #define HOUV_EPI(MET)                                                                                              \
@@ -249,7 +259,8 @@ __device__ __forceinline__ void epilogue(const Smem& sm, const float4* __restric
       bt[k] = btile[k][MET];                                                                                       \
     }                                                                                                              \
     epilogue_metric<BLOCK, Q, MET, DIR>(sm, refs, qx, qy, qz, bm, bt, count, (MET == 0) ? k_full : k_view, px, py, \
-                                        pz, sm.acc + (MET * 2 + DIR) * kAccStride HOUV_STAMP_ARG);                 \
+                                        pz, sm.acc + (MET * 2 + DIR) * kAccStride,                                 \
+                                        ws ? ws + (size_t)MET * ws_stride : nullptr HOUV_STAMP_ARG);               \
   }
   HOUV_EPI(0)
   if constexpr (NMET == 4) {
@@ -260,7 +271,7 @@ __device__ __forceinline__ void epilogue(const Smem& sm, const float4* __restric
 #undef HOUV_EPI
 }
 
-template <int BLOCK, int Q, int NMET>
+template <int BLOCK, int Q, int NMET, bool PRUNE>
 __global__ __launch_bounds__(BLOCK, 4) void solve_kernel(SolveArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int N = a.N, M = a.M;
@@ -281,6 +292,21 @@ __global__ __launch_bounds__(BLOCK, 4) void solve_kernel(SolveArgs a) {
   for (int j = N + tid; j < npad; j += BLOCK) sm.mov[j] = pad4;
   if (tid < 24) sm.state[tid] = a.state[(size_t)inst * 24 + tid];
   __syncthreads();
+  const int rot = tid & (kSub - 1);
+  short* ws_a = nullptr;   // NN of the moved points in the target (direction 1)
+  short* ws_b = nullptr;   // NN of the target points in the moved cloud (direction 0)
+  if constexpr (PRUNE) {
+    ws_b = a.nn_ws + ((size_t)inst * 2 + 0) * 4 * a.ws_stride;
+    ws_a = a.nn_ws + ((size_t)inst * 2 + 1) * 4 * a.ws_stride;
+    float tx0[Q], ty0[Q], tz0[Q];
+#pragma unroll
+    for (int k = 0; k < Q; ++k) {
+      const int i = k * BLOCK + tid;
+      const float4 v = (i < M) ? sm.tgt[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+      tx0[k] = v.x; ty0[k] = v.y; tz0[k] = v.z;
+    }
+    tile_boxes<BLOCK, Q>(tx0, ty0, tz0, M, mpad / kSub, sm.tbox);   // the target is static: boxes once per launch
+  }
   if (tid == 0) {
     float p[8];
 #pragma unroll
@@ -325,9 +351,21 @@ __global__ __launch_bounds__(BLOCK, 4) void solve_kernel(SolveArgs a) {
       __syncthreads();
       HOUV_STAMP(0);
       // ---- sweep A: moved -> target ----
-      sweep<Q, NMET>(sm.tgt, mpad / kSub, mx, my, mz, best, btile);
+      bool pruned_now = false;
+      if constexpr (PRUNE) {
+        tile_boxes<BLOCK, Q>(mx, my, mz, N, npad / kSub, sm.mbox);   // read by sweep B after the next barriers
+        pruned_now = (a.ws_valid != 0) || (it > 0);
+      }
+      if (pruned_now) {
+        if constexpr (PRUNE) {
+          pruned_sweep<Q, NMET>(sm.tgt, sm.tbox, mpad / kSub, mx, my, mz, ws_a, a.ws_stride, N, BLOCK, rot, best, btile);
+        }
+      } else {
+        sweep<Q, NMET>(sm.tgt, mpad / kSub, mx, my, mz, best, btile);
+      }
       HOUV_STAMP(1);
-      epilogue<BLOCK, Q, NMET, 1>(sm, sm.tgt, mx, my, mz, best, btile, N, a.k_full, a.k_view, sx, sy, sz HOUV_STAMP_ARG);
+      epilogue<BLOCK, Q, NMET, 1>(sm, sm.tgt, mx, my, mz, best, btile, N, a.k_full, a.k_view, sx, sy, sz, ws_a,
+                                  a.ws_stride HOUV_STAMP_ARG);
       HOUV_STAMP(2);
     }
     {
@@ -339,9 +377,17 @@ __global__ __launch_bounds__(BLOCK, 4) void solve_kernel(SolveArgs a) {
         const float4 v = (i < M) ? sm.tgt[i] : make_float4(0.f, 0.f, 0.f, 0.f);
         tx[k] = v.x; ty[k] = v.y; tz[k] = v.z;
       }
-      sweep<Q, NMET>(sm.mov, npad / kSub, tx, ty, tz, best, btile);
+      const bool pruned_now = PRUNE && ((a.ws_valid != 0) || (it > 0));
+      if (pruned_now) {
+        if constexpr (PRUNE) {
+          pruned_sweep<Q, NMET>(sm.mov, sm.mbox, npad / kSub, tx, ty, tz, ws_b, a.ws_stride, M, BLOCK, rot, best, btile);
+        }
+      } else {
+        sweep<Q, NMET>(sm.mov, npad / kSub, tx, ty, tz, best, btile);
+      }
       HOUV_STAMP(3);
-      epilogue<BLOCK, Q, NMET, 0>(sm, sm.mov, tx, ty, tz, best, btile, M, a.k_full, a.k_view, tx, ty, tz HOUV_STAMP_ARG);
+      epilogue<BLOCK, Q, NMET, 0>(sm, sm.mov, tx, ty, tz, best, btile, M, a.k_full, a.k_view, tx, ty, tz, ws_b,
+                                  a.ws_stride HOUV_STAMP_ARG);
       HOUV_STAMP(4);
     }
     __syncthreads();
@@ -424,19 +470,19 @@ __global__ __launch_bounds__(BLOCK, 4) void solve_kernel(SolveArgs a) {
   if (tid < 24) a.state[(size_t)inst * 24 + tid] = sm.state[tid];
 }
 
-template <int BLOCK, int Q>
+template <int BLOCK, int Q, bool PRUNE>
 int launch(const SolveArgs& a, int use_views, hipStream_t s) {
   const size_t bytes = smem_bytes(a.N, a.M, BLOCK);
   const int grid = a.P * a.K;
   hipError_t e;
   if (use_views) {
-    e = hipFuncSetAttribute((const void*)solve_kernel<BLOCK, Q, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    e = hipFuncSetAttribute((const void*)solve_kernel<BLOCK, Q, 4, PRUNE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     if (e != hipSuccess) { set_error("houv_solve_iterate: cannot reserve %zu B of LDS: %s", bytes, hipGetErrorString(e)); return 0; }
-    solve_kernel<BLOCK, Q, 4><<<grid, BLOCK, bytes, s>>>(a);
+    solve_kernel<BLOCK, Q, 4, PRUNE><<<grid, BLOCK, bytes, s>>>(a);
   } else {
-    e = hipFuncSetAttribute((const void*)solve_kernel<BLOCK, Q, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    e = hipFuncSetAttribute((const void*)solve_kernel<BLOCK, Q, 1, PRUNE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     if (e != hipSuccess) { set_error("houv_solve_iterate: cannot reserve %zu B of LDS: %s", bytes, hipGetErrorString(e)); return 0; }
-    solve_kernel<BLOCK, Q, 1><<<grid, BLOCK, bytes, s>>>(a);
+    solve_kernel<BLOCK, Q, 1, PRUNE><<<grid, BLOCK, bytes, s>>>(a);
   }
   return check_launch("houv_solve_iterate") ? 1 : 0;
 }
@@ -455,46 +501,78 @@ extern "C" int houv_debug_read_stamps(unsigned long long* host_out, int reset) {
 }
 #endif
 
-extern "C" int houv_solve_iterate(const float* src, const float* tgt, int P, int N, int M, int K, double* state,
-                                  int steps_done, int n_iters, int angle_base, int trans_mode, int use_views,
-                                  int f64_params, int k_full, int k_view, double lr, double beta1, double beta2,
-                                  double eps, float loss_scale, float* out_score, float* out_loss, float* out_R,
-                                  float* out_T, float* out_grad, float* out_cd, void* stream) {
+static int solve_dispatch(const float* src, const float* tgt, int P, int N, int M, int K, double* state, int steps_done,
+                          int n_iters, int angle_base, int trans_mode, int use_views, int f64_params, int k_full,
+                          int k_view, double lr, double beta1, double beta2, double eps, float loss_scale,
+                          float* out_score, float* out_loss, float* out_R, float* out_T, float* out_grad, float* out_cd,
+                          short* nn_ws, int ws_valid, int ws_stride, bool prune, void* stream, const char* who) {
   using namespace houv;
   if (P < 0 || N <= 0 || M <= 0 || K <= 0 || n_iters <= 0 || steps_done < 0 || angle_base < 0 || angle_base > 3 ||
       trans_mode < 0 || trans_mode > 1) {
-    set_error("houv_solve_iterate: bad argument P=%d N=%d M=%d K=%d n_iters=%d steps_done=%d base=%d trans_mode=%d", P,
-              N, M, K, n_iters, steps_done, angle_base, trans_mode);
+    set_error("%s: bad argument P=%d N=%d M=%d K=%d n_iters=%d steps_done=%d base=%d trans_mode=%d", who, P, N, M, K,
+              n_iters, steps_done, angle_base, trans_mode);
     return 0;
   }
   if (P == 0) return 1;
   if (!src || !tgt || !state) {
-    set_error("houv_solve_iterate: null pointer");
+    set_error("%s: null pointer", who);
     return 0;
   }
   // topk(k) over a direction with fewer than k points raises in the reference (model_utils_completion.py:91-92)
   const int kv = use_views ? k_view : 1;
   if (k_full < 1 || k_full > N || k_full > M || kv < 1 || kv > N || kv > M) {
-    set_error("houv_solve_iterate: top-k size out of range (k_full=%d k_view=%d N=%d M=%d)", k_full, k_view, N, M);
+    set_error("%s: top-k size out of range (k_full=%d k_view=%d N=%d M=%d)", who, k_full, k_view, N, M);
     return 0;
   }
   if ((long long)P * K > 0x7fffffffLL) {
-    set_error("houv_solve_iterate: too many hypotheses");
+    set_error("%s: too many hypotheses", who);
     return 0;
   }
   SolveArgs a{src, tgt, P, N, M, K, state, steps_done, n_iters, angle_base, trans_mode, f64_params, k_full, k_view,
-              lr, beta1, beta2, eps, loss_scale, out_score, out_loss, out_R, out_T, out_grad, out_cd};
+              lr, beta1, beta2, eps, loss_scale, out_score, out_loss, out_R, out_T, out_grad, out_cd, nn_ws, ws_valid,
+              ws_stride};
   hipStream_t s = (hipStream_t)stream;
   const int mx = N > M ? N : M;
   if (smem_bytes(N, M, 1024) > 160 * 1024) {
-    set_error("houv_solve_iterate: clouds of %d + %d points do not fit in 160 KiB of LDS", N, M);
+    set_error("%s: clouds of %d + %d points do not fit in 160 KiB of LDS", who, N, M);
     return 0;
   }
-  if (mx <= 256) return launch<256, 1>(a, use_views, s);
-  if (mx <= 512) return launch<256, 2>(a, use_views, s);
-  if (mx <= 1024) return launch<256, 4>(a, use_views, s);
-  if (mx <= 2048) return launch<512, 4>(a, use_views, s);
-  if (mx <= 4096) return launch<1024, 4>(a, use_views, s);
-  set_error("houv_solve_iterate: clouds larger than 4096 points are not supported (N=%d M=%d)", N, M);
+  if (prune) {
+    if (mx > 2048 || !nn_ws || ws_stride < mx) {
+      set_error("%s: pruned mode needs clouds of <= 2048 points (64 sub-tiles) and a workspace (ws_stride >= max(N,M))", who);
+      return 0;
+    }
+    if (mx <= 256) return launch<256, 1, true>(a, use_views, s);
+    if (mx <= 512) return launch<256, 2, true>(a, use_views, s);
+    if (mx <= 1024) return launch<256, 4, true>(a, use_views, s);
+    return launch<512, 4, true>(a, use_views, s);
+  }
+  if (mx <= 256) return launch<256, 1, false>(a, use_views, s);
+  if (mx <= 512) return launch<256, 2, false>(a, use_views, s);
+  if (mx <= 1024) return launch<256, 4, false>(a, use_views, s);
+  if (mx <= 2048) return launch<512, 4, false>(a, use_views, s);
+  if (mx <= 4096) return launch<1024, 4, false>(a, use_views, s);
+  set_error("%s: clouds larger than 4096 points are not supported (N=%d M=%d)", who, N, M);
   return 0;
+}
+
+extern "C" int houv_solve_iterate(const float* src, const float* tgt, int P, int N, int M, int K, double* state,
+                                  int steps_done, int n_iters, int angle_base, int trans_mode, int use_views,
+                                  int f64_params, int k_full, int k_view, double lr, double beta1, double beta2,
+                                  double eps, float loss_scale, float* out_score, float* out_loss, float* out_R,
+                                  float* out_T, float* out_grad, float* out_cd, void* stream) {
+  return solve_dispatch(src, tgt, P, N, M, K, state, steps_done, n_iters, angle_base, trans_mode, use_views, f64_params,
+                        k_full, k_view, lr, beta1, beta2, eps, loss_scale, out_score, out_loss, out_R, out_T, out_grad,
+                        out_cd, nullptr, 0, 0, false, stream, "houv_solve_iterate");
+}
+
+extern "C" int houv_solve_iterate_pruned(const float* src, const float* tgt, int P, int N, int M, int K, double* state,
+                                         int steps_done, int n_iters, int angle_base, int trans_mode, int use_views,
+                                         int f64_params, int k_full, int k_view, double lr, double beta1, double beta2,
+                                         double eps, float loss_scale, float* out_score, float* out_loss, float* out_R,
+                                         float* out_T, float* out_grad, float* out_cd, int16_t* nn_ws, int ws_valid,
+                                         int ws_stride, void* stream) {
+  return solve_dispatch(src, tgt, P, N, M, K, state, steps_done, n_iters, angle_base, trans_mode, use_views, f64_params,
+                        k_full, k_view, lr, beta1, beta2, eps, loss_scale, out_score, out_loss, out_R, out_T, out_grad,
+                        out_cd, (short*)nn_ws, ws_valid, ws_stride, true, stream, "houv_solve_iterate_pruned");
 }

@@ -94,7 +94,8 @@ def pose_forward(params, angle_base, trans_mode=0, src=None):
 
 
 def solve_iterate(src, tgt, state, K, *, steps_done, n_iters, angle_base, trans_mode, use_views, f64_params, k_full,
-                  k_view, lr, loss_scale, betas=(0.9, 0.999), eps=1e-8, want_grad=False, want_cd=False):
+                  k_view, lr, loss_scale, betas=(0.9, 0.999), eps=1e-8, want_grad=False, want_cd=False, nn_ws=None,
+                  ws_valid=False):
     """One launch of the fused HOUV loop (houv_solve_iterate).  ``state`` [P*K,24] fp64 is updated in place.
     Returns dict(score[P*K], loss[P*K], R[P*K,3,3], T[P*K,3][, grad[P*K,8]][, cd[P*K,8]]) of the LAST forward."""
     _lib.require_gpu(src, tgt, state)
@@ -113,14 +114,20 @@ def solve_iterate(src, tgt, state, K, *, steps_done, n_iters, angle_base, trans_
         out["grad"] = torch.empty((n, 8), dtype=_F32, device=dev)
     if want_cd:
         out["cd"] = torch.empty((n, 8), dtype=_F32, device=dev)
+    common = (_lib.ptr(src), _lib.ptr(tgt), P, N, M, int(K), _lib.ptr(state), int(steps_done), int(n_iters),
+              int(angle_base), int(trans_mode), int(bool(use_views)), int(bool(f64_params)), int(k_full), int(k_view),
+              float(lr), float(betas[0]), float(betas[1]), float(eps), float(loss_scale), _lib.ptr(out["score"]),
+              _lib.ptr(out["loss"]), _lib.ptr(out["R"]), _lib.ptr(out["T"]), _lib.ptr(out.get("grad")),
+              _lib.ptr(out.get("cd")))
     with torch.cuda.device(dev):
-        ok = _lib.load().houv_solve_iterate(
-            _lib.ptr(src), _lib.ptr(tgt), P, N, M, int(K), _lib.ptr(state), int(steps_done), int(n_iters),
-            int(angle_base), int(trans_mode), int(bool(use_views)), int(bool(f64_params)), int(k_full), int(k_view),
-            float(lr), float(betas[0]), float(betas[1]), float(eps), float(loss_scale), _lib.ptr(out["score"]),
-            _lib.ptr(out["loss"]), _lib.ptr(out["R"]), _lib.ptr(out["T"]), _lib.ptr(out.get("grad")),
-            _lib.ptr(out.get("cd")), _lib.stream_of(src))
-    _lib.check(ok, "houv_solve_iterate")
+        if nn_ws is None:
+            ok = _lib.load().houv_solve_iterate(*common, _lib.stream_of(src))
+        else:   # opt-in exact pruned search: nn_ws int16 [P*K, 2, 4, stride] persists between chunked launches
+            if nn_ws.dtype != torch.int16 or tuple(nn_ws.shape[:3]) != (n, 2, 4) or not nn_ws.is_contiguous():
+                raise _lib.HouvHipError("solve_iterate: nn_ws must be a contiguous int16 [P*K,2,4,stride] tensor")
+            ok = _lib.load().houv_solve_iterate_pruned(*common, _lib.ptr(nn_ws), int(bool(ws_valid)), nn_ws.shape[3],
+                                                       _lib.stream_of(src))
+    _lib.check(ok, "houv_solve_iterate" + ("_pruned" if nn_ws is not None else ""))
     return out
 
 

@@ -47,8 +47,31 @@ def solve_twin_init_params(n_inst):
     return np.concatenate([V, a, c, s], axis=1)
 
 
+# Opt-in exact pruned nearest-neighbour search (houv_solve_iterate_pruned).  Off by default: north_star specifies the
+# brute-force sweep, and that is what bench.py measures unless --solver pruned is given.
+PRUNED = False
+
+
+def morton_sort(cloud):
+    """Reorder every cloud [P,N,3] along a 30-bit Morton curve (spatially compact 32-point sub-tiles make the pruned
+    search effective; the result of a solve does not depend on the order of the points beyond fp32 summation order)."""
+    lo = cloud.min(dim=1, keepdim=True)[0]
+    hi = cloud.max(dim=1, keepdim=True)[0]
+    q = ((cloud - lo) / (hi - lo + 1e-9) * 1023.0).to(torch.int64).clamp_(0, 1023)
+
+    def spread(x):
+        x = (x | (x << 16)) & 0x030000FF
+        x = (x | (x << 8)) & 0x0300F00F
+        x = (x | (x << 4)) & 0x030C30C3
+        x = (x | (x << 2)) & 0x09249249
+        return x
+    code = spread(q[..., 0]) | (spread(q[..., 1]) << 1) | (spread(q[..., 2]) << 2)
+    order = torch.argsort(code, dim=1)
+    return torch.gather(cloud, 1, order.unsqueeze(2).expand(-1, -1, 3)).contiguous()
+
+
 def run_stage(src, tgt, params, K, n_iters, *, angle_base, trans_mode, use_views, f64_params, lr,
-              iters_per_launch=None, want_grad=False, want_cd=False, alpha=0.5):
+              iters_per_launch=None, want_grad=False, want_cd=False, alpha=0.5, pruned=None):
     """Run ``n_iters`` optimisation iterations for P*K hypotheses.  params: float64 [P*K,8] (numpy or tensor).
     Returns (out dict of the last forward, state tensor [P*K,24] fp64 after n_iters Adam steps)."""
     if n_iters < 1:
@@ -71,6 +94,11 @@ def run_stage(src, tgt, params, K, n_iters, *, angle_base, trans_mode, use_views
     k_full = int(N * alpha)            # model_utils_completion.py:85-86 with percent = alpha
     k_view = int(N * 1)
     step = iters_per_launch or ITERS_PER_LAUNCH
+    pruned = PRUNED if pruned is None else pruned
+    nn_ws = None
+    if pruned and max(N, tgt.shape[1]) <= 2048:
+        src, tgt = morton_sort(src), morton_sort(tgt)
+        nn_ws = torch.empty((n, 2, 4, max(N, tgt.shape[1])), dtype=torch.int16, device=dev)
     done, out = 0, None
     while done < n_iters:
         it = min(step, n_iters - done)
@@ -82,7 +110,7 @@ def run_stage(src, tgt, params, K, n_iters, *, angle_base, trans_mode, use_views
         out = ops.solve_iterate(src, tgt, state, K, steps_done=done, n_iters=it, angle_base=angle_base,
                                 trans_mode=trans_mode, use_views=use_views, f64_params=f64_params, k_full=k_full,
                                 k_view=k_view, lr=lr, loss_scale=1.0 / n, want_grad=want_grad and last,
-                                want_cd=want_cd and last)
+                                want_cd=want_cd and last, nn_ws=nn_ws, ws_valid=done > 0)
         if LAUNCH_LOG is not None:
             ev1.record(torch.cuda.current_stream(dev))
             LAUNCH_LOG.append((ev0, ev1, n, it, N, tgt.shape[1], bool(use_views)))

@@ -10,6 +10,8 @@ P, K, N, iters = int(os.environ.get("P", 32)), 64, 2048, int(os.environ.get("ITE
 src, tgt, _ = synthetic.make_pairs(P, N, seed=1)
 src, tgt = src.to(dev), tgt.to(dev)
 p0 = solver.houv_init_params(P * K)
+solver.PRUNED = bool(int(os.environ.get('PRUNED', '0')))
+src, tgt = solver.morton_sort(src), solver.morton_sort(tgt)
 lib = _lib.load()
 buf = (ctypes.c_ulonglong * 16)()
 for views in (True, False):
