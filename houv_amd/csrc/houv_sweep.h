@@ -113,120 +113,235 @@ __device__ __forceinline__ float4 recover_nn(const float4* __restrict__ rp, floa
 
 // ---------------------------------------------------------------------------------------------------------------
 // EXACT pruned sweep (opt-in, houv_solve_iterate_pruned).  References are grouped in the same 32-point sub-tiles as
-// the brute-force sweep; every sub-tile carries an axis-aligned bounding box.  For a query with an upper bound ub[m]
-// on its nearest-neighbour distance under metric m (the distance to the point that was its NN in the previous
-// iteration -- an actual point, so the bound is attained), a sub-tile whose box is farther than ub[m] for every
-// metric cannot contain any metric's NN and is skipped.  The surviving sub-tiles are visited in ascending order with
-// the same min3 / strict-< bookkeeping as sweep(), so (best, btile) come out BIT-IDENTICAL to the brute-force sweep.
-// Per-lane sub-tile lists are 64-bit masks; lanes walk their own lists (LDS gathers, scan order rotated per lane).
+// the brute-force sweep; every sub-tile carries an axis-aligned bounding box.  For every query and metric m the
+// distance to the point that was its NN in the previous iteration is an upper bound ub[m] that is attained; a sub-tile
+// whose box is farther from the query than ub[m] for every metric cannot contain any of its NNs -- nor a point tying
+// with one -- and is skipped.  The surviving sub-tiles are visited in ascending order with the same min3 / strict-<
+// bookkeeping as sweep(), so (best, btile) come out BIT-IDENTICAL to the brute-force sweep.
+//   * per-lane sub-tile lists are 64-bit masks (<= 64 sub-tiles, i.e. clouds of <= 2048 points);
+//   * lanes walk their own lists: LDS gathers, scan order XOR-rotated per lane (conflict-free, one v_xor per read),
+//     reads software-pipelined in batches of 4;
+//   * a lane's Q lists are walked back to back inside ONE loop, so a wave runs for the max over lanes of the SUMMED
+//     list lengths (measured 60 steps for 48.8 asked at 2048^2 with views) instead of the sum of per-list maxima (70).
+// Measured alternatives (profiles/r01_pruned_variants.txt): G neighbouring queries of a lane sharing one list and every
+// gathered reference (HOUV_PRUNE_OWN = HOUV_PRUNE_GROUP = 2 or 4) does fewer, fatter steps but neighbours' lists are
+// correlated, which costs more in lane imbalance than the shared reads save: 1.05 / 1.19 vs 1.04 us per hypothesis-
+// iteration.  The walk is ~60 % of the pruned iteration, the box tests ~10 %, the bounds ~2 %.
 // ---------------------------------------------------------------------------------------------------------------
-template <int Q, int NMET>
+#ifdef HOUV_STAMPS
+__device__ unsigned long long g_prune_stat[8];   // asked, steps, waves, cycles: bounds / masks / walk
+#define HOUV_PSTAMP(i) do { const unsigned long long n_ = __builtin_readcyclecounter(); if ((threadIdx.x & 63) == 0) atomicAdd(&g_prune_stat[i], n_ - pst_); pst_ = n_; } while (0)
+#else
+#define HOUV_PSTAMP(i) do {} while (0)
+#endif
+
+// point owned by (thread, k): a lane owns Q/OWN chunks of OWN consecutive points; chunk c of all lanes covers points
+// [c*BLOCK*OWN, (c+1)*BLOCK*OWN).  OWN = 1: strided (brute-force default), OWN = Q: Q consecutive points per lane.
+template <int BLOCK, int Q, int OWN>
+__device__ __forceinline__ int pt_index(int k) {
+  static_assert(OWN >= 1 && Q % OWN == 0 && kSub % OWN == 0, "ownership chunk must divide Q and the sub-tile");
+  return (k / OWN) * (BLOCK * OWN) + (int)threadIdx.x * OWN + (k % OWN);
+}
+
+typedef float houv_f4v __attribute__((ext_vector_type(4)));
+typedef const houv_f4v __attribute__((address_space(3))) * lds_f4;
+
+#ifndef HOUV_PRUNE_GROUP
+#define HOUV_PRUNE_GROUP 1
+#endif
+
+template <int BLOCK, int Q, int NMET, int OWN>
 __device__ __forceinline__ void pruned_sweep(const float4* __restrict__ refs, const float4* __restrict__ boxes, int ntile,
                                              const float (&qx)[Q], const float (&qy)[Q], const float (&qz)[Q],
-                                             const short* __restrict__ prev, int prev_stride, int count, int block,
-                                             int rot, float (&best)[Q][NMET], int (&btile)[Q][NMET]) {
-#pragma unroll   // static k: runtime-indexed register arrays would be demoted to scratch
-  for (int k = 0; k < Q; ++k) {
-    // upper bounds: the distance to last iteration's NN (an actual point, so the bound is attained); computed just in
-    // time per query to keep the register footprint of the tile walk small
-    float ubs[NMET];
-    {
-      const int i = k * block + (int)threadIdx.x;
-      const bool ok = i < count;
+                                             const short* __restrict__ prev, int prev_stride, int count, int rot,
+                                             float (&best)[Q][NMET], int (&btile)[Q][NMET]) {
+  // G queries share one sub-tile list and every gathered reference (G = 1 by default, see above); a lane's Q/G lists
+  // are walked back to back inside ONE loop (a lane moves on to its next list while others are still on their first)
+  constexpr int G = (OWN < HOUV_PRUNE_GROUP) ? OWN : HOUV_PRUNE_GROUP;
+  constexpr int L = Q / G;
+  unsigned long long un[L];
+#ifdef HOUV_STAMPS
+  unsigned long long pst_ = __builtin_readcyclecounter();
+#endif
+  {
+    float ub[Q][NMET];
 #pragma unroll
-      for (int m = 0; m < NMET; ++m) ubs[m] = INFINITY;
-      if (ok) {
-        { const float4 r = refs[prev[0 * prev_stride + i]]; ubs[0] = metric_sqdist<0>(r.x - qx[k], r.y - qy[k], r.z - qz[k]); }
-        if constexpr (NMET == 4) {
-          { const float4 r = refs[prev[1 * prev_stride + i]]; ubs[1] = metric_sqdist<1>(r.x - qx[k], r.y - qy[k], r.z - qz[k]); }
-          { const float4 r = refs[prev[2 * prev_stride + i]]; ubs[2] = metric_sqdist<2>(r.x - qx[k], r.y - qy[k], r.z - qz[k]); }
-          { const float4 r = refs[prev[3 * prev_stride + i]]; ubs[3] = metric_sqdist<3>(r.x - qx[k], r.y - qy[k], r.z - qz[k]); }
-        }
+    for (int k = 0; k < Q; ++k) {
+      const int i = pt_index<BLOCK, Q, OWN>(k);
+      const bool ok = i < count;
+      const int ii = ok ? i : 0;
+      { const float4 r = refs[prev[0 * prev_stride + ii]]; ub[k][0] = metric_sqdist<0>(r.x - qx[k], r.y - qy[k], r.z - qz[k]); }
+      if constexpr (NMET == 4) {
+        { const float4 r = refs[prev[1 * prev_stride + ii]]; ub[k][1] = metric_sqdist<1>(r.x - qx[k], r.y - qy[k], r.z - qz[k]); }
+        { const float4 r = refs[prev[2 * prev_stride + ii]]; ub[k][2] = metric_sqdist<2>(r.x - qx[k], r.y - qy[k], r.z - qz[k]); }
+        { const float4 r = refs[prev[3 * prev_stride + ii]]; ub[k][3] = metric_sqdist<3>(r.x - qx[k], r.y - qy[k], r.z - qz[k]); }
       }
 #pragma unroll
-      for (int m = 0; m < NMET; ++m) ubs[m] = ubs[m] * 1.00001f + 1e-30f;   // LB is rounded: keep the test conservative
+      for (int m = 0; m < NMET; ++m) ub[k][m] = ok ? (ub[k][m] * 1.00001f + 1e-30f) : -1.f;   // box distances are rounded: stay conservative
     }
-    unsigned long long un = 0ull;
+#pragma unroll
+    for (int g = 0; g < L; ++g) un[g] = 0ull;
+    HOUV_PSTAMP(3);
     for (int t = 0; t < ntile; ++t) {                 // wave-uniform: box reads are LDS broadcasts
       const float4 lo = boxes[2 * t], hi = boxes[2 * t + 1];
-      const float dx = fmaxf(fmaxf(lo.x - qx[k], qx[k] - hi.x), 0.f);
-      const float dy = fmaxf(fmaxf(lo.y - qy[k], qy[k] - hi.y), 0.f);
-      const float dz = fmaxf(fmaxf(lo.z - qz[k], qz[k] - hi.z), 0.f);
-      const float xx = dx * dx, yy = dy * dy, zz = dz * dz;
-      bool in = (xx + yy + zz) <= ubs[0];
-      if constexpr (NMET == 4) in = in || (yy + zz) <= ubs[1] || (xx + zz) <= ubs[2] || (xx + yy) <= ubs[3];
-      un |= in ? (1ull << t) : 0ull;
+#pragma unroll
+      for (int k = 0; k < Q; ++k) {
+        const float dx = fmaxf(fmaxf(lo.x - qx[k], qx[k] - hi.x), 0.f);
+        const float dy = fmaxf(fmaxf(lo.y - qy[k], qy[k] - hi.y), 0.f);
+        const float dz = fmaxf(fmaxf(lo.z - qz[k], qz[k] - hi.z), 0.f);
+        const float xx = dx * dx, yy = dy * dy, zz = dz * dz;
+        bool in = (xx + yy + zz) <= ub[k][0];
+        if constexpr (NMET == 4) in = in || (yy + zz) <= ub[k][1] || (xx + zz) <= ub[k][2] || (xx + yy) <= ub[k][3];
+        un[k / G] |= in ? (1ull << t) : 0ull;
+      }
     }
-    float bk[NMET];
-    int tk[NMET];
+  }
 #pragma unroll
-    for (int m = 0; m < NMET; ++m) { bk[m] = INFINITY; tk[m] = 0; }
-    while (__any(un != 0ull)) {
-      const bool act = un != 0ull;
-      const int t = act ? (__ffsll((long long)un) - 1) : 0;
-      un = act ? (un & (un - 1ull)) : 0ull;
-      const float4* rp = refs + t * kSub;
-      float tm[NMET];
+  for (int k = 0; k < Q; ++k)
 #pragma unroll
-      for (int m = 0; m < NMET; ++m) tm[m] = INFINITY;
-#pragma unroll 1
-      for (int j0 = 0; j0 < kSub; j0 += 8) {
-        // 8 gathered reads issued back to back, ONE wait, then 4 x (two references) of arithmetic
-        float4 r[8];
+    for (int m = 0; m < NMET; ++m) { best[k][m] = INFINITY; btile[k][m] = 0; }
+#ifdef HOUV_STAMPS
+  {
+    int asked = 0;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) r[u] = rp[(j0 + u + rot) & (kSub - 1)];
+    for (int g = 0; g < L; ++g) asked += __popcll(un[g]);
 #pragma unroll
-        for (int u = 0; u < 8; ++u) asm volatile("" ::"v"(r[u].x), "v"(r[u].y), "v"(r[u].z), "v"(r[u].w));   // keep b128
+    for (int o = 1; o < 64; o <<= 1) asked += __shfl_xor(asked, o, 64);
+    if ((threadIdx.x & 63) == 0) {
+      atomicAdd(&g_prune_stat[0], (unsigned long long)asked);           // sub-tile visits the wave's lanes asked for
+      atomicAdd(&g_prune_stat[2], 1ull);                                // waves
+    }
+  }
+  HOUV_PSTAMP(4);
+  unsigned long long steps_ = 0;
+#endif
+  for (;;) {
+    // current list of this lane: the first one that still has sub-tiles
+    unsigned long long mm = 0ull;
+    int cur = 0;
 #pragma unroll
-        for (int u = 0; u < 8; u += 2) {
-          const float4 a = r[u], c = r[u + 1];
-          const float ax = a.x - qx[k], ay = a.y - qy[k], az = a.z - qz[k];
-          const float cx = c.x - qx[k], cy = c.y - qy[k], cz = c.z - qz[k];
+    for (int g = L - 1; g >= 0; --g) {
+      const bool has = un[g] != 0ull;
+      mm = has ? un[g] : mm;
+      cur = has ? g : cur;
+    }
+    if (!__any(mm != 0ull)) break;
+#ifdef HOUV_STAMPS
+    ++steps_;   // sub-tile steps the wave executed
+#endif
+    const bool act = mm != 0ull;
+    const int t = act ? (__ffsll((long long)mm) - 1) : 0;
+    mm = act ? (mm & (mm - 1ull)) : 0ull;
+    float cx[G], cy[G], cz[G];
+#pragma unroll
+    for (int k = 0; k < G; ++k) { cx[k] = qx[k]; cy[k] = qy[k]; cz[k] = qz[k]; }
+#pragma unroll
+    for (int g = 0; g < L; ++g) {
+      un[g] = (cur == g) ? mm : un[g];
+      if (g > 0) {
+#pragma unroll
+        for (int k = 0; k < G; ++k) {
+          cx[k] = (cur == g) ? qx[g * G + k] : cx[k];
+          cy[k] = (cur == g) ? qy[g * G + k] : cy[k];
+          cz[k] = (cur == g) ? qz[g * G + k] : cz[k];
+        }
+      }
+    }
+    // scan order rotated per lane by XOR: reference j of the sub-tile sits at byte (j ^ rot) * 16 -- one v_xor per read;
+    // needs the clouds 512-B aligned in LDS (solve.hip aligns the dynamic segment), conflict-free as (lane ^ j) % 16
+    // takes 16 distinct slots in every ds_read_b128 lane group
+    const unsigned xa = (unsigned)(size_t)(lds_f4)refs + (unsigned)t * (kSub * 16u) + ((unsigned)rot << 4);
+    float tm[G][NMET];
+#pragma unroll
+    for (int k = 0; k < G; ++k)
+#pragma unroll
+      for (int m = 0; m < NMET; ++m) tm[k][m] = INFINITY;
+    // gathered reads are software-pipelined: while a batch of kBatch references is being evaluated the next batch is
+    // already in flight (ping-pong register sets; the trailing prefetch wraps around and is dropped)
+    constexpr int kBatch = 4;
+    auto fetch = [&](float4 (&r)[kBatch], int j0) {
+#pragma unroll
+      for (int u = 0; u < kBatch; ++u) {
+        const houv_f4v v = *(lds_f4)(size_t)(xa ^ ((unsigned)((j0 + u) & (kSub - 1)) << 4));
+        r[u] = make_float4(v.x, v.y, v.z, v.w);
+      }
+    };
+    auto eval = [&](float4 (&r)[kBatch]) {
+#pragma unroll
+      for (int u = 0; u < kBatch; ++u) asm volatile("" ::"v"(r[u].x), "v"(r[u].y), "v"(r[u].z), "v"(r[u].w));   // keep b128
+#pragma unroll
+      for (int u = 0; u < kBatch; u += 2) {
+        const float4 a = r[u], c = r[u + 1];
+#pragma unroll
+        for (int k = 0; k < G; ++k) {
+          const float ax = a.x - cx[k], ay = a.y - cy[k], az = a.z - cz[k];
+          const float bx = c.x - cx[k], by = c.y - cy[k], bz = c.z - cz[k];
           if constexpr (NMET == 4) {
-            const float axx = ax * ax, ayy = ay * ay, cxx = cx * cx, cyy = cy * cy;
-            const float a3 = __builtin_fmaf(ay, ay, axx), c3 = __builtin_fmaf(cy, cy, cxx);
-            const float a1 = __builtin_fmaf(az, az, ayy), c1 = __builtin_fmaf(cz, cz, cyy);
-            const float a2 = __builtin_fmaf(az, az, axx), c2 = __builtin_fmaf(cz, cz, cxx);
-            const float a0 = __builtin_fmaf(az, az, a3), c0 = __builtin_fmaf(cz, cz, c3);
-            tm[0] = min3f(tm[0], a0, c0);
-            tm[1] = min3f(tm[1], a1, c1);
-            tm[2] = min3f(tm[2], a2, c2);
-            tm[3] = min3f(tm[3], a3, c3);
+            const float axx = ax * ax, ayy = ay * ay, bxx = bx * bx, byy = by * by;
+            const float a3 = __builtin_fmaf(ay, ay, axx), b3 = __builtin_fmaf(by, by, bxx);
+            const float a1 = __builtin_fmaf(az, az, ayy), b1 = __builtin_fmaf(bz, bz, byy);
+            const float a2 = __builtin_fmaf(az, az, axx), b2 = __builtin_fmaf(bz, bz, bxx);
+            const float a0 = __builtin_fmaf(az, az, a3), b0 = __builtin_fmaf(bz, bz, b3);
+            tm[k][0] = min3f(tm[k][0], a0, b0);
+            tm[k][1] = min3f(tm[k][1], a1, b1);
+            tm[k][2] = min3f(tm[k][2], a2, b2);
+            tm[k][3] = min3f(tm[k][3], a3, b3);
           } else {
-            tm[0] = min3f(tm[0], metric_sqdist<0>(ax, ay, az), metric_sqdist<0>(cx, cy, cz));
+            tm[k][0] = min3f(tm[k][0], metric_sqdist<0>(ax, ay, az), metric_sqdist<0>(bx, by, bz));
           }
         }
       }
-#pragma unroll
-      for (int m = 0; m < NMET; ++m) {
-        const bool lt = act && (tm[m] < bk[m]);
-        bk[m] = lt ? tm[m] : bk[m];
-        tk[m] = lt ? t : tk[m];
-      }
+    };
+    float4 ra[kBatch], rb[kBatch];
+    fetch(ra, 0);
+#pragma unroll 1
+    for (int j0 = 0; j0 < kSub; j0 += 2 * kBatch) {
+      fetch(rb, j0 + kBatch);
+      eval(ra);
+      fetch(ra, j0 + 2 * kBatch);
+      eval(rb);
     }
 #pragma unroll
-    for (int m = 0; m < NMET; ++m) { best[k][m] = bk[m]; btile[k][m] = tk[m]; }
+    for (int g = 0; g < L; ++g)
+#pragma unroll
+      for (int k = 0; k < G; ++k)
+#pragma unroll
+        for (int m = 0; m < NMET; ++m) {
+          const bool lt = act && (cur == g) && (tm[k][m] < best[g * G + k][m]);
+          best[g * G + k][m] = lt ? tm[k][m] : best[g * G + k][m];
+          btile[g * G + k][m] = lt ? t : btile[g * G + k][m];
+        }
   }
+#ifdef HOUV_STAMPS
+  if ((threadIdx.x & 63) == 0) atomicAdd(&g_prune_stat[1], steps_);
+  HOUV_PSTAMP(5);
+#endif
 }
 
-// Axis-aligned boxes of the 32-point sub-tiles of a cloud whose point (k*BLOCK + tid) lives in this lane's registers:
-// a sub-tile is one 32-lane half of a wave, so five xor-shuffles per coordinate reduce it.  box[2t] = lo, box[2t+1] = hi.
-template <int BLOCK, int Q>
+// Axis-aligned boxes of the 32-point sub-tiles of a cloud whose points live in this lane's registers (ownership as
+// pt_index): within a chunk a sub-tile spans 32/OWN consecutive lanes x OWN points; an in-lane min/max plus a few
+// xor-shuffles reduce it.  box[2t] = lo, box[2t+1] = hi.
+template <int BLOCK, int Q, int OWN>
 __device__ __forceinline__ void tile_boxes(const float (&x)[Q], const float (&y)[Q], const float (&z)[Q], int count,
                                            int ntile, float4* __restrict__ box) {
 #pragma unroll
-  for (int k = 0; k < Q; ++k) {
-    const int i = k * BLOCK + threadIdx.x;
-    const bool ok = i < count;
-    float lx = ok ? x[k] : INFINITY, ly = ok ? y[k] : INFINITY, lz = ok ? z[k] : INFINITY;
-    float hx = ok ? x[k] : -INFINITY, hy = ok ? y[k] : -INFINITY, hz = ok ? z[k] : -INFINITY;
+  for (int c = 0; c < Q / OWN; ++c) {
+    float lx = INFINITY, ly = INFINITY, lz = INFINITY, hx = -INFINITY, hy = -INFINITY, hz = -INFINITY;
 #pragma unroll
-    for (int o = 1; o < 32; o <<= 1) {
+    for (int o = 0; o < OWN; ++o) {
+      const int k = c * OWN + o;
+      if (pt_index<BLOCK, Q, OWN>(k) < count) {
+        lx = fminf(lx, x[k]); ly = fminf(ly, y[k]); lz = fminf(lz, z[k]);
+        hx = fmaxf(hx, x[k]); hy = fmaxf(hy, y[k]); hz = fmaxf(hz, z[k]);
+      }
+    }
+#pragma unroll
+    for (int o = 1; o < kSub / OWN; o <<= 1) {
       lx = fminf(lx, __shfl_xor(lx, o, 64)); ly = fminf(ly, __shfl_xor(ly, o, 64)); lz = fminf(lz, __shfl_xor(lz, o, 64));
       hx = fmaxf(hx, __shfl_xor(hx, o, 64)); hy = fmaxf(hy, __shfl_xor(hy, o, 64)); hz = fmaxf(hz, __shfl_xor(hz, o, 64));
     }
-    const int t = i >> 5;
-    if ((threadIdx.x & 31) == 0 && t < ntile) {
+    const int t = pt_index<BLOCK, Q, OWN>(c * OWN) / kSub;
+    if (((int)threadIdx.x % (kSub / OWN)) == 0 && t < ntile) {
       box[2 * t] = make_float4(lx, ly, lz, 0.f);
       box[2 * t + 1] = make_float4(hx, hy, hz, 0.f);
     }

@@ -176,7 +176,7 @@ __device__ __forceinline__ void select_smallest(const unsigned (&key)[Q], int ks
 // Recovers the exact NN, selects the ksel smallest distances, and reduces
 //   S = sum sqrt(d),  G = sum c,  GP = sum c p^T,   c = mask * (moved - target) / sqrt(d),  p = un-moved source point
 // over the selection into acc_out[0..13).
-template <int BLOCK, int Q, int MET, int DIR>
+template <int BLOCK, int Q, int MET, int DIR, int OWN>
 __device__ __forceinline__ void epilogue_metric(const Smem& sm, const float4* __restrict__ refs, const float (&qx)[Q],
                                                 const float (&qy)[Q], const float (&qz)[Q], const float (&bestm)[Q],
                                                 const int (&btilem)[Q], int count, int ksel, const float (&px)[Q],
@@ -191,9 +191,9 @@ __device__ __forceinline__ void epilogue_metric(const Smem& sm, const float4* __
     const float bd = bestm[k];
     int jn;
     const float4 nn = recover_nn<MET, kRescanBatch>(refs + btilem[k] * kSub, qx[k], qy[k], qz[k], bd, rot, jn);
-    if (ws && (k * BLOCK + tid) < count) ws[k * BLOCK + tid] = (short)(btilem[k] * kSub + jn);
+    if (ws && pt_index<BLOCK, Q, OWN>(k) < count) ws[pt_index<BLOCK, Q, OWN>(k)] = (short)(btilem[k] * kSub + jn);
     nx[k] = nn.x; ny[k] = nn.y; nz[k] = nn.z;
-    const bool valid = (k * BLOCK + tid) < count;
+    const bool valid = pt_index<BLOCK, Q, OWN>(k) < count;
     key[k] = valid ? __float_as_uint(bd) : 0xFFFFFFFFu;
     sel[k] = valid;
   }
@@ -244,7 +244,7 @@ __device__ __forceinline__ void epilogue_metric(const Smem& sm, const float4* __
   HOUV_STAMP(11);
 }
 
-template <int BLOCK, int Q, int NMET, int DIR>
+template <int BLOCK, int Q, int NMET, int DIR, int OWN>
 __device__ __forceinline__ void epilogue(const Smem& sm, const float4* __restrict__ refs, const float (&qx)[Q],
                                          const float (&qy)[Q], const float (&qz)[Q], const float (&best)[Q][NMET],
                                          const int (&btile)[Q][NMET], int count, int k_full, int k_view,
@@ -258,7 +258,7 @@ __device__ __forceinline__ void epilogue(const Smem& sm, const float4* __restric
       bm[k] = best[k][MET];                                                                                        \
       bt[k] = btile[k][MET];                                                                                       \
     }                                                                                                              \
-    epilogue_metric<BLOCK, Q, MET, DIR>(sm, refs, qx, qy, qz, bm, bt, count, (MET == 0) ? k_full : k_view, px, py, \
+    epilogue_metric<BLOCK, Q, MET, DIR, OWN>(sm, refs, qx, qy, qz, bm, bt, count, (MET == 0) ? k_full : k_view, px, py, \
                                         pz, sm.acc + (MET * 2 + DIR) * kAccStride,                                 \
                                         ws ? ws + (size_t)MET * ws_stride : nullptr HOUV_STAMP_ARG);               \
   }
@@ -271,9 +271,12 @@ __device__ __forceinline__ void epilogue(const Smem& sm, const float4* __restric
 #undef HOUV_EPI
 }
 
-template <int BLOCK, int Q, int NMET, bool PRUNE>
+// PRUNE: the exact pruned search of houv_sweep.h.  OWN: a lane owns Q/OWN chunks of OWN consecutive points (pt_index);
+// 1 (strided, coalesced loads) everywhere by default -- other values are build-time experiments of the pruned mode
+// (HOUV_PRUNE_OWN), for which <PRUNE=false, OWN> is the brute-force sweep under the same summation order (ws_valid=-1).
+template <int BLOCK, int Q, int NMET, bool PRUNE, int OWN>
 __global__ __launch_bounds__(BLOCK, 4) void solve_kernel(SolveArgs a) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  extern __shared__ __attribute__((aligned(512))) unsigned char smem_raw[];   // 512 B: pruned_sweep's XOR-rotated gathers
   const int N = a.N, M = a.M;
   const Smem sm = carve(smem_raw, N, M, BLOCK);
   const int tid = threadIdx.x;
@@ -301,11 +304,11 @@ __global__ __launch_bounds__(BLOCK, 4) void solve_kernel(SolveArgs a) {
     float tx0[Q], ty0[Q], tz0[Q];
 #pragma unroll
     for (int k = 0; k < Q; ++k) {
-      const int i = k * BLOCK + tid;
+      const int i = pt_index<BLOCK, Q, OWN>(k);
       const float4 v = (i < M) ? sm.tgt[i] : make_float4(0.f, 0.f, 0.f, 0.f);
       tx0[k] = v.x; ty0[k] = v.y; tz0[k] = v.z;
     }
-    tile_boxes<BLOCK, Q>(tx0, ty0, tz0, M, mpad / kSub, sm.tbox);   // the target is static: boxes once per launch
+    tile_boxes<BLOCK, Q, OWN>(tx0, ty0, tz0, M, mpad / kSub, sm.tbox);   // the target is static: boxes once per launch
   }
   if (tid == 0) {
     float p[8];
@@ -337,7 +340,7 @@ __global__ __launch_bounds__(BLOCK, 4) void solve_kernel(SolveArgs a) {
       for (int i = 0; i < 3; ++i) T[i] = sm.pose[9 + i];
 #pragma unroll
       for (int k = 0; k < Q; ++k) {
-        const int i = k * BLOCK + tid;
+        const int i = pt_index<BLOCK, Q, OWN>(k);
         const bool ok = i < N;
         sx[k] = ok ? src[i * 3 + 0] : 0.f;
         sy[k] = ok ? src[i * 3 + 1] : 0.f;
@@ -353,18 +356,18 @@ __global__ __launch_bounds__(BLOCK, 4) void solve_kernel(SolveArgs a) {
       // ---- sweep A: moved -> target ----
       bool pruned_now = false;
       if constexpr (PRUNE) {
-        tile_boxes<BLOCK, Q>(mx, my, mz, N, npad / kSub, sm.mbox);   // read by sweep B after the next barriers
+        tile_boxes<BLOCK, Q, OWN>(mx, my, mz, N, npad / kSub, sm.mbox);   // read by sweep B after the next barriers
         pruned_now = (a.ws_valid != 0) || (it > 0);
       }
       if (pruned_now) {
         if constexpr (PRUNE) {
-          pruned_sweep<Q, NMET>(sm.tgt, sm.tbox, mpad / kSub, mx, my, mz, ws_a, a.ws_stride, N, BLOCK, rot, best, btile);
+          pruned_sweep<BLOCK, Q, NMET, OWN>(sm.tgt, sm.tbox, mpad / kSub, mx, my, mz, ws_a, a.ws_stride, N, rot, best, btile);
         }
       } else {
         sweep<Q, NMET>(sm.tgt, mpad / kSub, mx, my, mz, best, btile);
       }
       HOUV_STAMP(1);
-      epilogue<BLOCK, Q, NMET, 1>(sm, sm.tgt, mx, my, mz, best, btile, N, a.k_full, a.k_view, sx, sy, sz, ws_a,
+      epilogue<BLOCK, Q, NMET, 1, OWN>(sm, sm.tgt, mx, my, mz, best, btile, N, a.k_full, a.k_view, sx, sy, sz, ws_a,
                                   a.ws_stride HOUV_STAMP_ARG);
       HOUV_STAMP(2);
     }
@@ -373,20 +376,20 @@ __global__ __launch_bounds__(BLOCK, 4) void solve_kernel(SolveArgs a) {
       float tx[Q], ty[Q], tz[Q];
 #pragma unroll
       for (int k = 0; k < Q; ++k) {
-        const int i = k * BLOCK + tid;
+        const int i = pt_index<BLOCK, Q, OWN>(k);
         const float4 v = (i < M) ? sm.tgt[i] : make_float4(0.f, 0.f, 0.f, 0.f);
         tx[k] = v.x; ty[k] = v.y; tz[k] = v.z;
       }
       const bool pruned_now = PRUNE && ((a.ws_valid != 0) || (it > 0));
       if (pruned_now) {
         if constexpr (PRUNE) {
-          pruned_sweep<Q, NMET>(sm.mov, sm.mbox, npad / kSub, tx, ty, tz, ws_b, a.ws_stride, M, BLOCK, rot, best, btile);
+          pruned_sweep<BLOCK, Q, NMET, OWN>(sm.mov, sm.mbox, npad / kSub, tx, ty, tz, ws_b, a.ws_stride, M, rot, best, btile);
         }
       } else {
         sweep<Q, NMET>(sm.mov, npad / kSub, tx, ty, tz, best, btile);
       }
       HOUV_STAMP(3);
-      epilogue<BLOCK, Q, NMET, 0>(sm, sm.mov, tx, ty, tz, best, btile, M, a.k_full, a.k_view, tx, ty, tz, ws_b,
+      epilogue<BLOCK, Q, NMET, 0, OWN>(sm, sm.mov, tx, ty, tz, best, btile, M, a.k_full, a.k_view, tx, ty, tz, ws_b,
                                   a.ws_stride HOUV_STAMP_ARG);
       HOUV_STAMP(4);
     }
@@ -470,19 +473,19 @@ __global__ __launch_bounds__(BLOCK, 4) void solve_kernel(SolveArgs a) {
   if (tid < 24) a.state[(size_t)inst * 24 + tid] = sm.state[tid];
 }
 
-template <int BLOCK, int Q, bool PRUNE>
+template <int BLOCK, int Q, bool PRUNE, int OWN>
 int launch(const SolveArgs& a, int use_views, hipStream_t s) {
   const size_t bytes = smem_bytes(a.N, a.M, BLOCK);
   const int grid = a.P * a.K;
   hipError_t e;
   if (use_views) {
-    e = hipFuncSetAttribute((const void*)solve_kernel<BLOCK, Q, 4, PRUNE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    e = hipFuncSetAttribute((const void*)solve_kernel<BLOCK, Q, 4, PRUNE, OWN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     if (e != hipSuccess) { set_error("houv_solve_iterate: cannot reserve %zu B of LDS: %s", bytes, hipGetErrorString(e)); return 0; }
-    solve_kernel<BLOCK, Q, 4, PRUNE><<<grid, BLOCK, bytes, s>>>(a);
+    solve_kernel<BLOCK, Q, 4, PRUNE, OWN><<<grid, BLOCK, bytes, s>>>(a);
   } else {
-    e = hipFuncSetAttribute((const void*)solve_kernel<BLOCK, Q, 1, PRUNE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    e = hipFuncSetAttribute((const void*)solve_kernel<BLOCK, Q, 1, PRUNE, OWN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     if (e != hipSuccess) { set_error("houv_solve_iterate: cannot reserve %zu B of LDS: %s", bytes, hipGetErrorString(e)); return 0; }
-    solve_kernel<BLOCK, Q, 1, PRUNE><<<grid, BLOCK, bytes, s>>>(a);
+    solve_kernel<BLOCK, Q, 1, PRUNE, OWN><<<grid, BLOCK, bytes, s>>>(a);
   }
   return check_launch("houv_solve_iterate") ? 1 : 0;
 }
@@ -491,6 +494,14 @@ int launch(const SolveArgs& a, int use_views, hipStream_t s) {
 }  // namespace houv
 
 #ifdef HOUV_STAMPS
+extern "C" int houv_debug_read_prune_stats(unsigned long long* host_out, int reset) {
+  if (hipMemcpyFromSymbol(host_out, HIP_SYMBOL(houv::g_prune_stat), sizeof(unsigned long long) * 8) != hipSuccess) return 0;
+  if (reset) {
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(houv::g_prune_stat), z, sizeof(z)) != hipSuccess) return 0;
+  }
+  return 1;
+}
 extern "C" int houv_debug_read_stamps(unsigned long long* host_out, int reset) {
   if (hipMemcpyFromSymbol(host_out, HIP_SYMBOL(houv::g_stamp), sizeof(unsigned long long) * 16) != hipSuccess) return 0;
   if (reset) {
@@ -500,6 +511,13 @@ extern "C" int houv_debug_read_stamps(unsigned long long* host_out, int reset) {
   return 1;
 }
 #endif
+
+// pruned mode: consecutive points a lane owns per chunk (pt_index), for kernels with Q = 2 / Q = 4 points per lane
+#ifndef HOUV_PRUNE_OWN
+#define HOUV_PRUNE_OWN 1
+#endif
+constexpr int kOwn2 = HOUV_PRUNE_OWN < 2 ? HOUV_PRUNE_OWN : 2;
+constexpr int kOwn4 = HOUV_PRUNE_OWN;
 
 static int solve_dispatch(const float* src, const float* tgt, int P, int N, int M, int K, double* state, int steps_done,
                           int n_iters, int angle_base, int trans_mode, int use_views, int f64_params, int k_full,
@@ -542,16 +560,23 @@ static int solve_dispatch(const float* src, const float* tgt, int P, int N, int 
       set_error("%s: pruned mode needs clouds of <= 2048 points (64 sub-tiles) and a workspace (ws_stride >= max(N,M))", who);
       return 0;
     }
-    if (mx <= 256) return launch<256, 1, true>(a, use_views, s);
-    if (mx <= 512) return launch<256, 2, true>(a, use_views, s);
-    if (mx <= 1024) return launch<256, 4, true>(a, use_views, s);
-    return launch<512, 4, true>(a, use_views, s);
+    if (ws_valid < 0) {   // test aid: the brute-force sweep under the pruned kernel's point ownership / summation order
+      a.ws_valid = 0;
+      if (mx <= 256) return launch<256, 1, false, 1>(a, use_views, s);
+      if (mx <= 512) return launch<256, 2, false, kOwn2>(a, use_views, s);
+      if (mx <= 1024) return launch<256, 4, false, kOwn4>(a, use_views, s);
+      return launch<512, 4, false, kOwn4>(a, use_views, s);
+    }
+    if (mx <= 256) return launch<256, 1, true, 1>(a, use_views, s);
+    if (mx <= 512) return launch<256, 2, true, kOwn2>(a, use_views, s);
+    if (mx <= 1024) return launch<256, 4, true, kOwn4>(a, use_views, s);
+    return launch<512, 4, true, kOwn4>(a, use_views, s);
   }
-  if (mx <= 256) return launch<256, 1, false>(a, use_views, s);
-  if (mx <= 512) return launch<256, 2, false>(a, use_views, s);
-  if (mx <= 1024) return launch<256, 4, false>(a, use_views, s);
-  if (mx <= 2048) return launch<512, 4, false>(a, use_views, s);
-  if (mx <= 4096) return launch<1024, 4, false>(a, use_views, s);
+  if (mx <= 256) return launch<256, 1, false, 1>(a, use_views, s);
+  if (mx <= 512) return launch<256, 2, false, 1>(a, use_views, s);
+  if (mx <= 1024) return launch<256, 4, false, 1>(a, use_views, s);
+  if (mx <= 2048) return launch<512, 4, false, 1>(a, use_views, s);
+  if (mx <= 4096) return launch<1024, 4, false, 1>(a, use_views, s);
   set_error("%s: clouds larger than 4096 points are not supported (N=%d M=%d)", who, N, M);
   return 0;
 }

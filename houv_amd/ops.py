@@ -125,7 +125,7 @@ def solve_iterate(src, tgt, state, K, *, steps_done, n_iters, angle_base, trans_
         else:   # opt-in exact pruned search: nn_ws int16 [P*K, 2, 4, stride] persists between chunked launches
             if nn_ws.dtype != torch.int16 or tuple(nn_ws.shape[:3]) != (n, 2, 4) or not nn_ws.is_contiguous():
                 raise _lib.HouvHipError("solve_iterate: nn_ws must be a contiguous int16 [P*K,2,4,stride] tensor")
-            ok = _lib.load().houv_solve_iterate_pruned(*common, _lib.ptr(nn_ws), int(bool(ws_valid)), nn_ws.shape[3],
+            ok = _lib.load().houv_solve_iterate_pruned(*common, _lib.ptr(nn_ws), -1 if ws_valid == "verify" else int(bool(ws_valid)), nn_ws.shape[3],
                                                        _lib.stream_of(src))
     _lib.check(ok, "houv_solve_iterate" + ("_pruned" if nn_ws is not None else ""))
     return out

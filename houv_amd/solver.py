@@ -110,7 +110,8 @@ def run_stage(src, tgt, params, K, n_iters, *, angle_base, trans_mode, use_views
         out = ops.solve_iterate(src, tgt, state, K, steps_done=done, n_iters=it, angle_base=angle_base,
                                 trans_mode=trans_mode, use_views=use_views, f64_params=f64_params, k_full=k_full,
                                 k_view=k_view, lr=lr, loss_scale=1.0 / n, want_grad=want_grad and last,
-                                want_cd=want_cd and last, nn_ws=nn_ws, ws_valid=done > 0)
+                                want_cd=want_cd and last, nn_ws=nn_ws,
+                                ws_valid="verify" if pruned == "verify" else done > 0)
         if LAUNCH_LOG is not None:
             ev1.record(torch.cuda.current_stream(dev))
             LAUNCH_LOG.append((ev0, ev1, n, it, N, tgt.shape[1], bool(use_views)))

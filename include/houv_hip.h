@@ -93,13 +93,14 @@ int houv_solve_iterate(const float* src, const float* tgt, int P, int N, int M, 
                        float* out_score, float* out_loss, float* out_R, float* out_T,
                        float* out_grad, float* out_cd, void* stream);
 
-/* Opt-in EXACT accelerated form of houv_solve_iterate (same arguments, same outputs bit for bit when given the same
- * clouds): every query remembers its nearest neighbour of the previous iteration; the distance to that point is an
+/* Opt-in EXACT accelerated form of houv_solve_iterate (same arguments, same search result): every query remembers its nearest neighbour of the previous iteration; the distance to that point is an
  * attained upper bound, and 32-point sub-tiles whose bounding box lies farther than the bound for all metrics are
- * skipped.  Works best on spatially sorted clouds (houv_amd.solver sorts them along a Morton curve).
+ * skipped.  Works best on spatially sorted clouds (houv_amd.solver sorts them along a Morton curve).  The search result
+ * and the summation order are those of houv_solve_iterate: same outputs BIT FOR BIT when given the same clouds.
  *   nn_ws[P*K, 2, 4, ws_stride] int16  workspace, in/out (previous NN index per hypothesis / direction / metric / point)
  *   ws_valid   0: nn_ws holds nothing yet (the first iteration of this call runs the brute-force sweep)
  *              1: nn_ws was left by the previous call on the same hypotheses (chunked launches)
+ *             -1: verification mode: every iteration runs the brute-force sweep (nn_ws is not used)
  * Limits: N, M <= 2048 (64 sub-tiles per cloud). */
 int houv_solve_iterate_pruned(const float* src, const float* tgt, int P, int N, int M, int K,
                               double* state, int steps_done, int n_iters,

@@ -1,7 +1,7 @@
 """Diagnostic: per-phase wave-cycle shares of solve_kernel from the -DHOUV_STAMPS build (make -C houv_amd/csrc stamps)."""
 import ctypes, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-os.environ["HOUV_HIP_LIB"] = os.path.join(ROOT, "houv_amd", "lib", "libhouv_hip_stamps.so")
+os.environ["HOUV_HIP_LIB"] = os.environ.get("HOUV_STAMPS_LIB", os.path.join(ROOT, "houv_amd", "lib", "libhouv_hip_stamps.so"))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
 from houv_amd import _lib, solver, synthetic

@@ -281,7 +281,8 @@ def test_solve_twin_end_to_end_vs_oracle(golden, dev):
 def test_pruned_search_is_bit_identical_to_brute_force(dev, N, M, views, f64, tm):
     """The opt-in pruned search (previous-NN upper bound + sub-tile bounding boxes) must reproduce the brute-force
     kernel BIT FOR BIT on the same clouds: scores, losses, poses, gradients, the 8 Chamfer terms and the optimiser state,
-    across chunked launches (workspace carried over) and bases."""
+    across chunked launches (workspace carried over) and bases -- against houv_solve_iterate itself and against the
+    pruned entry point's verification mode (ws_valid=-1, pruning switched off)."""
     from houv_amd import solver, synthetic
     P, K = 3, 26
     src, tgt, _ = synthetic.make_pairs(P, max(N, M), seed=31)
@@ -291,6 +292,10 @@ def test_pruned_search_is_bit_identical_to_brute_force(dev, N, M, views, f64, tm
     kw = dict(angle_base=1, trans_mode=tm, use_views=views, f64_params=f64, lr=0.1 if f64 else 0.01, want_grad=True,
               want_cd=True)
     ref, st_ref = solver.run_stage(src, tgt, p0, K, 23, iters_per_launch=50, pruned=False, **kw)
+    ver, st_ver = solver.run_stage(src, tgt, p0, K, 23, iters_per_launch=50, pruned="verify", **kw)
+    for key in ("score", "loss", "R", "T", "grad", "cd"):
+        assert torch.equal(ver[key], ref[key]), key
+    assert torch.equal(st_ver, st_ref)
     for chunk in (50, 7):
         # run_stage re-sorts sorted clouds (a no-op permutation), so both modes see identical point orders
         out, st = solver.run_stage(src, tgt, p0, K, 23, iters_per_launch=chunk, pruned=True, **kw)
