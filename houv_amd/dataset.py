@@ -1,6 +1,6 @@
 """Data side of the path: the pose samplers of registration/dataset.py:16-52 and Dataset classes with the tuple layouts the
 HOUV drivers unpack (val: the 17-tuple of dataset.py:346, test: (src, tgt, label) of :348; sharded [l:r] slices of
-MVP_RG_rotated_bound, :369-372).  Real MVP ``*.h5`` files need h5py (optional); ``SyntheticRG`` serves MVP-shaped
+MVP_RG_rotated_bound, :369-372).  Real MVP ``*.h5`` files are read by houv_amd.io (h5py or hdf5_min); ``SyntheticRG`` serves MVP-shaped
 synthetic pairs with the same layouts when they are absent."""
 import numpy as np
 import torch
@@ -76,7 +76,7 @@ class SyntheticRG(_PairsBase):
 
 class MVP_RG_rotated(_PairsBase):
     """registration/dataset.py:189-348 for prefix in {"val", "test"} (what HOUV's drivers use): needs the MVP h5 files
-    and h5py.  val serves the stored rotated clouds + transforms (:312-323), test the rotated test clouds (:205-207)."""
+    (not shipped).  val serves the stored rotated clouds + transforms (:312-323), test the rotated test clouds (:205-207)."""
     FILES = {"train": "./data/MVP_Train_RG.h5", "val": "./data/MVP_Test_RG.h5", "test": "./data/MVP_ExtraTest_RG.h5"}
 
     def __init__(self, prefix, args, l=None, r=None):

@@ -1,0 +1,167 @@
+"""houv_amd.hdf5_min against real HDF5: fixtures written by libhdf5 1.10.6 (tests/golden/make_golden_h5.py) for the
+reader, and -- where this image has them (/opt/conda) -- h5dump and libhdf5.so themselves reading what the writer emits.
+CPU only."""
+import ctypes
+import os
+import shutil
+import subprocess
+import zipfile
+
+import numpy as np
+import pytest
+
+from houv_amd import hdf5_min
+from houv_amd import io as hio
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+EXPECTED = np.load(os.path.join(GOLD, "g10_g11_expected.npz"))
+H5DUMP = shutil.which("h5dump") or ("/opt/conda/bin/h5dump" if os.path.exists("/opt/conda/bin/h5dump") else None)
+LIBHDF5 = os.environ.get("HOUV_HDF5_LIB") or ("/opt/conda/lib/libhdf5.so" if os.path.exists("/opt/conda/lib/libhdf5.so")
+                                              else None)
+
+
+@pytest.mark.parametrize("fixture", ["g10_mvp_like.h5", "g11_latest.h5"])
+def test_reader_matches_libhdf5_fixtures(fixture):
+    """Every storage flavour libhdf5 produced -- contiguous, compact, chunked via B-tree v1 (two levels) or fixed
+    array (paged), gzip / shuffle / fletcher32, big-endian, nested group, dense links -- reads back bit-exact."""
+    with hdf5_min.H5File(os.path.join(GOLD, fixture)) as f:
+        assert sorted(f.keys()) == sorted({k.split("__")[0] for k in EXPECTED.files})
+        assert "src" in f and "nope" not in f and "extra/complete" in f
+        with pytest.raises(KeyError):
+            f["nope"]
+        for key in EXPECTED.files:
+            want = EXPECTED[key]
+            ds = f[key.replace("__", "/")]
+            assert ds.shape == want.shape and ds.dtype.newbyteorder("=") == want.dtype, key
+            got = np.array(ds)
+            assert got.dtype == want.dtype and np.array_equal(got, want), key
+            assert np.array_equal(ds[...], want) and len(ds) == want.shape[0]
+            n = want.shape[0]
+            for lo, hi in ((0, 1), (1, n - 1), (n - 1, n), (2, 2), (n // 2, n + 5)):     # dataset.py:369-372 slices
+                assert np.array_equal(ds[lo:hi], want[lo:hi]), (key, lo, hi)
+            assert np.array_equal(ds[-1], want[-1]) and np.array_equal(ds[1], want[1])
+            if want.ndim > 1:
+                assert np.array_equal(ds[1:3, 0], want[1:3, 0])
+        assert isinstance(f["extra"], hdf5_min.Group) and f["extra"].keys() == ["complete"]
+
+
+def test_load_mvp_rg_reads_the_keys_the_reference_reads():
+    """io.load_mvp_rg (dataset.py:205-238) on the MVP-shaped fixture, whole and as an [l:r] shard."""
+    path = os.path.join(GOLD, "g10_mvp_like.h5")
+    d = hio.load_mvp_rg(path)
+    for k in ("src", "tgt", "rotated_src", "rotated_tgt", "transforms", "pose_src", "cat_labels", "match_level",
+              "match_id", "rot_level"):
+        assert np.array_equal(d[k], EXPECTED[k]), k
+    assert "complete" not in d and "pose_tgt" not in d                   # absent keys are skipped, not errors
+    s = hio.load_mvp_rg(path, 2, 5)
+    assert s["src"].shape == (3, 64, 3) and np.array_equal(s["cat_labels"], EXPECTED["cat_labels"][2:5])
+    with pytest.raises(RuntimeError):
+        hio.load_mvp_rg(os.path.join(GOLD, "no_such_file.h5"))
+
+
+def _cases():
+    rng = np.random.default_rng(7)
+    return {
+        "results": rng.standard_normal((9, 4, 4)).astype(np.float32),
+        "f64": rng.standard_normal((3, 5)),
+        "i64": rng.integers(-2**40, 2**40, 11),
+        "i32": rng.integers(-2**30, 2**30, (2, 3, 4)).astype(np.int32),
+        "i16": rng.integers(-2**15, 2**15, 7).astype(np.int16),
+        "u8": rng.integers(0, 255, (4, 4)).astype(np.uint8),
+        "u64": rng.integers(0, 2**63, 3).astype(np.uint64),
+        "scalar": np.float32(2.5),
+        "empty": np.zeros((0, 3), np.float32),
+        "be": rng.standard_normal(6).astype(">f4"),
+        "noncontig": rng.standard_normal((6, 6)).astype(np.float32)[::2, ::3],
+    }
+
+
+def test_writer_reader_round_trip(tmp_path):
+    cases = _cases()
+    path = hdf5_min.write_h5(str(tmp_path / "rt.h5"), cases)
+    with hdf5_min.H5File(path) as f:
+        assert sorted(f.keys()) == sorted(cases)
+        for k, a in cases.items():
+            got = np.array(f[k])
+            assert got.shape == np.shape(a) and np.array_equal(got, np.asarray(a)), k
+            assert got.dtype == np.asarray(a).dtype.newbyteorder("="), k
+    many = {"d%02d" % i: np.full((2,), i, np.int32) for i in range(40)}          # one symbol node with 40 entries
+    with hdf5_min.H5File(hdf5_min.write_h5(str(tmp_path / "many.h5"), many)) as f:
+        assert all(int(f[k][0]) == int(k[1:]) for k in many)
+    with pytest.raises(hdf5_min.H5FormatError):
+        hdf5_min.write_h5(str(tmp_path / "bad.h5"), {"s": np.array(["a", "b"])})
+    with pytest.raises(ValueError):
+        hdf5_min.write_h5(str(tmp_path / "bad.h5"), {"a/b": np.zeros(3)})
+
+
+def test_reader_refuses_what_it_does_not_understand(tmp_path):
+    p = tmp_path / "junk.h5"
+    p.write_bytes(b"not an hdf5 file at all" * 100)
+    with pytest.raises(hdf5_min.H5FormatError):
+        hdf5_min.H5File(str(p))
+    (tmp_path / "empty.h5").write_bytes(b"")
+    with pytest.raises(hdf5_min.H5FormatError):
+        hdf5_min.H5File(str(tmp_path / "empty.h5"))
+    with pytest.raises(ValueError):
+        hdf5_min.H5File(os.path.join(GOLD, "g10_mvp_like.h5"), "w")
+
+
+def test_save_results_writes_results_h5_and_submission_zip(tmp_path):
+    """test.py:70-76: results.h5 with dataset 'results' f32 [N,4,4], zipped as submission.zip."""
+    res = np.random.default_rng(3).standard_normal((12, 4, 4)).astype(np.float32)
+    out = hio.save_results(str(tmp_path), res)
+    assert out.endswith("results.h5")
+    assert np.array_equal(hio.load_results(out), res)
+    assert np.array_equal(hio.load_results(os.path.join(str(tmp_path), "results.npy")), res)
+    with zipfile.ZipFile(os.path.join(str(tmp_path), "submission.zip")) as z:
+        assert z.namelist() == ["results.h5"]
+        z.extract("results.h5", str(tmp_path / "unzipped"))
+    assert np.array_equal(hio.load_results(str(tmp_path / "unzipped" / "results.h5")), res)
+
+
+@pytest.mark.skipif(H5DUMP is None, reason="no h5dump in this image")
+def test_h5dump_reads_the_writer_output(tmp_path):
+    """The real HDF5 tools accept the file: header listing and a binary dump of every dataset."""
+    cases = _cases()
+    path = hdf5_min.write_h5(str(tmp_path / "w.h5"), cases)
+    hdr = subprocess.run([H5DUMP, "-H", path], capture_output=True, text=True)
+    assert hdr.returncode == 0 and not hdr.stderr.strip(), hdr.stderr
+    assert 'DATASET "results"' in hdr.stdout and "H5T_IEEE_F32LE" in hdr.stdout and "( 9, 4, 4 )" in hdr.stdout
+    for k, a in cases.items():
+        a = np.asarray(a)
+        if a.size == 0:
+            continue
+        binf = str(tmp_path / (k + ".bin"))
+        r = subprocess.run([H5DUMP, "-d", "/" + k, "-b", "LE", "-o", binf, path], capture_output=True, text=True)
+        assert r.returncode == 0 and not r.stderr.strip(), (k, r.stderr)
+        got = np.fromfile(binf, dtype=a.dtype.newbyteorder("<")).reshape(a.shape)
+        assert np.array_equal(got, a), k
+
+
+@pytest.mark.skipif(LIBHDF5 is None, reason="no libhdf5.so in this image")
+def test_libhdf5_reads_the_writer_output(tmp_path):
+    """H5Fopen / H5Dopen2 / H5Dread of libhdf5 itself on results.h5 as save_results writes it."""
+    res = np.random.default_rng(5).standard_normal((7, 4, 4)).astype(np.float32)
+    path = hio.save_results(str(tmp_path), res)
+    if hio.h5py is not None:
+        pytest.skip("h5py wrote this file")
+    lib = ctypes.CDLL(LIBHDF5)
+    hid = ctypes.c_int64
+    lib.H5open()
+    lib.H5Fopen.restype, lib.H5Fopen.argtypes = hid, [ctypes.c_char_p, ctypes.c_uint, hid]
+    lib.H5Dopen2.restype, lib.H5Dopen2.argtypes = hid, [hid, ctypes.c_char_p, hid]
+    lib.H5Dread.restype, lib.H5Dread.argtypes = ctypes.c_int, [hid, hid, hid, hid, hid, ctypes.c_void_p]
+    lib.H5Dget_storage_size.restype, lib.H5Dget_storage_size.argtypes = ctypes.c_uint64, [hid]
+    lib.H5Dclose.argtypes = [hid]
+    lib.H5Fclose.argtypes = [hid]
+    f = lib.H5Fopen(path.encode(), 0, 0)
+    assert f >= 0
+    d = lib.H5Dopen2(f, b"results", 0)
+    assert d >= 0
+    assert lib.H5Dget_storage_size(d) == res.nbytes
+    out = np.empty_like(res)
+    native_float = hid.in_dll(lib, "H5T_NATIVE_FLOAT_g").value
+    assert lib.H5Dread(d, native_float, 0, 0, 0, out.ctypes.data_as(ctypes.c_void_p)) >= 0
+    assert np.array_equal(out, res)
+    lib.H5Dclose(d)
+    assert lib.H5Fclose(f) >= 0
