@@ -276,7 +276,7 @@ def main():
     flops = evals * FLOP_PER_EVAL
     achieved = flops / (k_ms * 1e-3) / 1e12
     roofline = {
-        "kernel": "houv::solve_kernel<512,4,4,%s>" % ("true" if args.solver == "pruned" else "false"), "bound": "mfma",
+        "kernel": "houv::solve_kernel<512, 4, 4, %s, 1>" % ("true" if args.solver == "pruned" else "false"), "bound": "mfma",
         "bound_note": "compute bound on the fp32 VALU issue rate; the kernel issues no MFMA -- `peak` is MI355X's dense "
                       "fp32 rate, which is the same 157.3 TFLOP/s for the vector ALUs and for fp32-input MFMA",
         "achieved": achieved, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP32_PEAK_TFLOPS,
