@@ -1,6 +1,8 @@
 """Host driver of the fused HOUV loop: parameter initialisation (host numpy, exactly as the reference draws
 it), chunked launches of houv_solve_iterate, and the best-of-K + angle-window retry logic shared by
 ``solve_model`` (registration/models/houv.py:142-206) and ``solve`` (registration/train_utils.py:467-572)."""
+import os
+
 import numpy as np
 import torch
 
@@ -48,8 +50,10 @@ def solve_twin_init_params(n_inst):
 
 
 # Opt-in exact pruned nearest-neighbour search (houv_solve_iterate_pruned).  Off by default: north_star specifies the
-# brute-force sweep, and that is what bench.py measures unless --solver pruned is given.
-PRUNED = False
+# brute-force sweep, and that is what bench.py measures unless --solver pruned is given.  Switch it on with
+# ``houv_amd.solver.PRUNED = True`` or HOUV_SOLVER=pruned in the environment (clouds of <= 2048 points; larger ones
+# silently take the brute-force kernel).
+PRUNED = os.environ.get("HOUV_SOLVER", "brute").strip().lower() == "pruned"
 
 
 def morton_sort(cloud):
