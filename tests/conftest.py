@@ -12,6 +12,10 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the CPU oracle runs many tiny torch ops: on a box that shows hundreds of host cores the default intra-op pool is
+    # several times slower than a small one
+    import torch
+    torch.set_num_threads(max(1, min(8, os.cpu_count() or 1)))
 
 
 @pytest.fixture(scope="session")

@@ -142,14 +142,14 @@ def test_solve_model_end_to_end_golden(golden, dev):
 
 
 def test_end_to_end_statistical_vs_oracle(dev):
-    """Top rung: full solve_model (200 iterations, retry stage) on 6 synthetic 128-pt pairs, K=26: trajectories are
+    """Top rung: full solve_model (200 iterations, retry stage) on 4 synthetic 128-pt pairs, K=26: trajectories are
     chaotic beyond ~50 iterations, so compare the distribution: the mean final score and mean RotE must agree with
     the CPU oracle's within the oracle's own sensitivity to a 1e-7 input perturbation (x3 margin, floor 0.5 deg)."""
     from houv_amd import synthetic
     from houv_amd.models.houv import HOUV, solve_model
     from houv_amd.train_utils import rotation_error
-    src, tgt, pose = synthetic.make_pairs(6, 128, seed=99)
-    r_gpu, t_gpu, ans = solve_model(HOUV(6 * 26, 0), src.to(dev), tgt.to(dev), pose.to(dev), kernel=26, num_epochs=200)
+    src, tgt, pose = synthetic.make_pairs(4, 128, seed=99)
+    r_gpu, t_gpu, ans = solve_model(HOUV(4 * 26, 0), src.to(dev), tgt.to(dev), pose.to(dev), kernel=26, num_epochs=200)
     r_ref, t_ref, ans_ref = orc.solve_model(src, tgt, pose, kernel=26, num_epochs=200)
     r_pert, _, _ = orc.solve_model(src * (1 + 1e-7), tgt, pose, kernel=26, num_epochs=200)
     spread = float((r_ref - r_pert).abs().mean())
