@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""G12: end-to-end statistics of the REAL reference's solve_model over 64 synthetic MVP-shaped pairs (BASELINE.md §3,
+last parity gate: "end-to-end statistical agreement of mean RotE/transE ... over >= 64 synthetic pairs").
+
+Run ONLY in the build container (needs /root/reference, CPU only, ~10 minutes):
+
+    python tests/golden/make_golden_stat.py
+
+64 pairs x 128 points from houv_amd.synthetic (seed 777), solved by registration/models/houv.py:solve_model with
+kernel=26, num_epochs=200 in 4 batches of 16 (the loss scale is 1/(B*K) per batch, houv.py:124).  Trajectories are
+chaotic beyond ~50 iterations (registration/README.md:82-91), so a second run on inputs perturbed by a relative 1e-7
+is stored beside the first: their difference is the reference's own run-to-run spread, which the test uses as its
+yardstick.  Only data is written: tests/golden/g12_stat.npz."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+from make_golden import import_reference  # noqa: E402
+
+
+def main():
+    torch.set_num_threads(8)
+    _, houv, _, _, _ = import_reference()
+    from houv_amd import synthetic
+    P, N, K, EPOCHS, BATCH = 64, 128, 26, 200, 16
+    src, tgt, pose = synthetic.make_pairs(P, N, seed=777)
+    out = dict(src=src.numpy(), tgt=tgt.numpy(), pose=pose.numpy(), kernel=np.int64(K), num_epochs=np.int64(EPOCHS),
+               batch=np.int64(BATCH))
+    for tag, scale in (("ref", 1.0), ("pert", 1.0 + 1e-7)):
+        r_all, t_all, a_all = [], [], []
+        for b in range(0, P, BATCH):
+            s = (src[b:b + BATCH] * scale).float()
+            r, t, ans = houv.solve_model(houv.HOUV(BATCH * K, 0), s, tgt[b:b + BATCH], pose[b:b + BATCH], kernel=K,
+                                         num_epochs=EPOCHS)
+            r_all.append(r.detach().numpy()); t_all.append(t.detach().numpy()); a_all.append(ans.detach().numpy())
+            print(tag, b, "RotE", np.round(r_all[-1], 2), flush=True)
+        out[tag + "_r_err"] = np.concatenate(r_all)
+        out[tag + "_t_err"] = np.concatenate(t_all)
+        out[tag + "_ans"] = np.concatenate(a_all)
+    np.savez_compressed(os.path.join(HERE, "g12_stat.npz"), **out)
+    for tag in ("ref", "pert"):
+        r, t = out[tag + "_r_err"], out[tag + "_t_err"]
+        print(tag, "mean RotE %.3f median %.3f solved(<5deg) %.3f mean transE %.4f" %
+              (r.mean(), np.median(r), (r < 5).mean(), t.mean()))
+
+
+if __name__ == "__main__":
+    main()
