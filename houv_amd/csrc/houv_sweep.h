@@ -7,6 +7,9 @@ namespace houv {
 
 constexpr int kAccStride = 16;   // row stride (floats) of the per-wave reduction scratch
 
+typedef float houv_f4v __attribute__((ext_vector_type(4)));
+typedef const houv_f4v __attribute__((address_space(3))) * lds_f4;   // LDS pointer usable from a 32-bit byte address
+
 // ------------------------------------------------------------------------------------------------
 // The brute-force sweep: for each of this lane's Q queries, min over all references of the NMET
 // squared distances, plus the id of the 32-reference sub-tile that produced each minimum.
@@ -87,29 +90,39 @@ __device__ __forceinline__ void block_sum(float (&v)[NV], float* red, float* out
 
 
 // Exact NN recovery for one query: re-evaluate the winning 32-reference sub-tile with the bit-identical expression
-// and return the lowest matching reference.  The scan order is rotated by `rot` (= lane id & 31): sub-tile bases are
-// 512 B apart, so an un-rotated scan puts all lanes of a ds_read_b128 group on the same LDS bank quad.
-template <int MET, int BATCH>
+// and return the lowest matching reference.  The scan order is rotated per lane (rot = lane id & 31): sub-tile bases
+// are 512 B apart, so an un-rotated scan puts all lanes of a ds_read_b128 group on the same LDS bank quad.  XOR512:
+// the cloud is 512-B aligned in LDS, so the rotation is an XOR on the byte address (one v_xor per read); otherwise
+// it is (j + rot) mod 32.
+template <int MET, int BATCH, bool XOR512 = false>
 __device__ __forceinline__ float4 recover_nn(const float4* __restrict__ rp, float qx, float qy, float qz, float bd, int rot,
                                              int& j_out) {
   int jb = kSub;
+  const unsigned xa = (unsigned)(size_t)(lds_f4)rp + ((unsigned)rot << 4);
 #pragma unroll 1
   for (int c = 0; c < kSub; c += BATCH) {
     float4 r[BATCH];
 #pragma unroll
-    for (int u = 0; u < BATCH; ++u) r[u] = rp[(c + u + rot) & (kSub - 1)];
+    for (int u = 0; u < BATCH; ++u) {
+      if constexpr (XOR512) {
+        const houv_f4v v = *(lds_f4)(size_t)(xa ^ ((unsigned)(c + u) << 4));
+        r[u] = make_float4(v.x, v.y, v.z, v.w);
+      } else {
+        r[u] = rp[(c + u + rot) & (kSub - 1)];
+      }
+    }
 #pragma unroll
     for (int u = 0; u < BATCH; ++u) asm volatile("" ::"v"(r[u].x), "v"(r[u].y), "v"(r[u].z), "v"(r[u].w));   // keep b128
 #pragma unroll
     for (int u = 0; u < BATCH; ++u) {
       const float d = metric_sqdist<MET>(r[u].x - qx, r[u].y - qy, r[u].z - qz);
-      jb = min(jb, (d == bd) ? ((c + u + rot) & (kSub - 1)) : kSub);   // lowest matching index, whatever the order
+      const int j = XOR512 ? ((c + u) ^ rot) : ((c + u + rot) & (kSub - 1));
+      jb = min(jb, (d == bd) ? j : kSub);   // lowest matching index, whatever the order
     }
   }
   j_out = jb & (kSub - 1);
   return rp[j_out];
 }
-
 
 // ---------------------------------------------------------------------------------------------------------------
 // EXACT pruned sweep (opt-in, houv_solve_iterate_pruned).  References are grouped in the same 32-point sub-tiles as
@@ -142,9 +155,6 @@ __device__ __forceinline__ int pt_index(int k) {
   static_assert(OWN >= 1 && Q % OWN == 0 && kSub % OWN == 0, "ownership chunk must divide Q and the sub-tile");
   return (k / OWN) * (BLOCK * OWN) + (int)threadIdx.x * OWN + (k % OWN);
 }
-
-typedef float houv_f4v __attribute__((ext_vector_type(4)));
-typedef const houv_f4v __attribute__((address_space(3))) * lds_f4;
 
 #ifndef HOUV_PRUNE_GROUP
 #define HOUV_PRUNE_GROUP 1

@@ -190,7 +190,7 @@ __device__ __forceinline__ void epilogue_metric(const Smem& sm, const float4* __
   for (int k = 0; k < Q; ++k) {
     const float bd = bestm[k];
     int jn;
-    const float4 nn = recover_nn<MET, kRescanBatch>(refs + btilem[k] * kSub, qx[k], qy[k], qz[k], bd, rot, jn);
+    const float4 nn = recover_nn<MET, kRescanBatch, true>(refs + btilem[k] * kSub, qx[k], qy[k], qz[k], bd, rot, jn);
     if (ws && pt_index<BLOCK, Q, OWN>(k) < count) ws[pt_index<BLOCK, Q, OWN>(k)] = (short)(btilem[k] * kSub + jn);
     nx[k] = nn.x; ny[k] = nn.y; nz[k] = nn.z;
     const bool valid = pt_index<BLOCK, Q, OWN>(k) < count;

@@ -4,7 +4,8 @@ last parity gate: "end-to-end statistical agreement of mean RotE/transE ... over
 
 Run ONLY in the build container (needs /root/reference, CPU only, ~10 minutes):
 
-    python tests/golden/make_golden_stat.py
+    python tests/golden/make_golden_stat.py            # G12: 128 points, reference + perturbed run
+    python tests/golden/make_golden_stat.py 512        # G13: BASELINE configs[0]'s size (64 pairs x 512 points), reference run only
 
 64 pairs x 128 points from houv_amd.synthetic (seed 777), solved by registration/models/houv.py:solve_model with
 kernel=26, num_epochs=200 in 4 batches of 16 (the loss scale is 1/(B*K) per batch, houv.py:124).  Trajectories are
@@ -27,11 +28,14 @@ def main():
     torch.set_num_threads(8)
     _, houv, _, _, _ = import_reference()
     from houv_amd import synthetic
-    P, N, K, EPOCHS, BATCH = 64, 128, 26, 200, 16
+    N = int(sys.argv[1]) if len(sys.argv) > 1 else 128
+    P, K, EPOCHS, BATCH = 64, 26, 200, 16
+    name = "g12_stat.npz" if N == 128 else "g13_stat%d.npz" % N
+    runs = (("ref", 1.0), ("pert", 1.0 + 1e-7)) if N == 128 else (("ref", 1.0),)
     src, tgt, pose = synthetic.make_pairs(P, N, seed=777)
     out = dict(src=src.numpy(), tgt=tgt.numpy(), pose=pose.numpy(), kernel=np.int64(K), num_epochs=np.int64(EPOCHS),
                batch=np.int64(BATCH))
-    for tag, scale in (("ref", 1.0), ("pert", 1.0 + 1e-7)):
+    for tag, scale in runs:
         r_all, t_all, a_all = [], [], []
         for b in range(0, P, BATCH):
             s = (src[b:b + BATCH] * scale).float()
@@ -42,8 +46,8 @@ def main():
         out[tag + "_r_err"] = np.concatenate(r_all)
         out[tag + "_t_err"] = np.concatenate(t_all)
         out[tag + "_ans"] = np.concatenate(a_all)
-    np.savez_compressed(os.path.join(HERE, "g12_stat.npz"), **out)
-    for tag in ("ref", "pert"):
+    np.savez_compressed(os.path.join(HERE, name), **out)
+    for tag, _ in runs:
         r, t = out[tag + "_r_err"], out[tag + "_t_err"]
         print(tag, "mean RotE %.3f median %.3f solved(<5deg) %.3f mean transE %.4f" %
               (r.mean(), np.median(r), (r < 5).mean(), t.mean()))
