@@ -295,6 +295,9 @@ def main():
         "valu_pipe_frac_sweeps": (inst_iters * 2.0 * args.points * args.points / 64 * 26.75) /
                                  (k_ms * 1e-3 * 2.4e9 * 1024),
     }
+    if args.solver == "pruned":
+        roofline["pruned_note"] = ("opt-in exact pruned search: `achieved` still counts the brute-force sweep's flops, so "
+                                   "frac > 1 only says that evaluations were provably skipped; it is not a roofline claim")
     out = {
         "metric": "registration pairs/sec (2048-pt partial pairs)", "value": n_total * args.steps / dt,
         "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
