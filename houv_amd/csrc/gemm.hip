@@ -47,8 +47,12 @@ __device__ __forceinline__ float4 load4_guarded(const float* __restrict__ p, int
   return v;
 }
 
-template <int BN, bool BT>
-__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
+// WPE: waves per SIMD the register allocation must allow.  1 = unconstrained (172 registers, 2 waves): best for long K,
+// where the MFMA stream dominates; 3 (<= 168 registers): best for K <= 256, where prologue, staging and the epilogue
+// of a workgroup have to hide behind other workgroups (measured: conv 64->128 41.7 -> 48.1, Q K^T 61 -> 72 TFLOP/s,
+// but 4096^3 109.6 -> 102.6).
+template <int BN, bool BT, int WPE>
+__global__ __launch_bounds__(256, WPE) void gemm_f32_kernel(GemmArgs g) {
   constexpr int LDA = BM + 1;                         // k-major tiles, +1 breaks the transposing writes' conflicts
   constexpr int LDB = BT ? (BN + 1) : (BN + 4);       // the [K,N] form is written with 16-byte stores
   constexpr int NI = BN / 64;                         // 32-wide MFMA tiles per wave along N
@@ -204,12 +208,16 @@ extern "C" int houv_gemm_f32(const float* A, const float* B, float* C, int M, in
   hipStream_t s = (hipStream_t)stream;
   const bool narrow = N <= 64;
   dim3 grid((N + (narrow ? 64 : 128) - 1) / (narrow ? 64 : 128), (M + BM - 1) / BM, outer * inner);
+  const bool short_k = K <= 256;
   if (narrow) {
-    if (trans_b) gemm_f32_kernel<64, true><<<grid, 256, 0, s>>>(g);
-    else gemm_f32_kernel<64, false><<<grid, 256, 0, s>>>(g);
+    if (trans_b) gemm_f32_kernel<64, true, 3><<<grid, 256, 0, s>>>(g);
+    else gemm_f32_kernel<64, false, 3><<<grid, 256, 0, s>>>(g);
+  } else if (short_k) {
+    if (trans_b) gemm_f32_kernel<128, true, 3><<<grid, 256, 0, s>>>(g);
+    else gemm_f32_kernel<128, false, 3><<<grid, 256, 0, s>>>(g);
   } else {
-    if (trans_b) gemm_f32_kernel<128, true><<<grid, 256, 0, s>>>(g);
-    else gemm_f32_kernel<128, false><<<grid, 256, 0, s>>>(g);
+    if (trans_b) gemm_f32_kernel<128, true, 1><<<grid, 256, 0, s>>>(g);
+    else gemm_f32_kernel<128, false, 1><<<grid, 256, 0, s>>>(g);
   }
   return check_launch("houv_gemm_f32") ? 1 : 0;
 }
