@@ -74,6 +74,64 @@ def morton_sort(cloud):
     return torch.gather(cloud, 1, order.unsqueeze(2).expand(-1, -1, 3)).contiguous()
 
 
+FUSED_MAX_POINTS = 4096     # both clouds of a hypothesis live in LDS inside the fused kernel (houv_solve_iterate)
+
+
+def _run_stage_unfused(src, tgt, params, K, n_iters, *, angle_base, trans_mode, use_views, f64_params, lr, want_grad,
+                       want_cd, alpha):
+    """Clouds too large for the fused kernel's LDS: the loop in the reference's own shape -- differentiable forward
+    (houv.py:94-103 / train_utils.py:113-148), Chamfer through the stand-alone HIP op (houv_chamfer_forward/backward,
+    any size), torch.topk, autograd and torch.optim.Adam -- everything on the GPU, ~an order of magnitude slower per
+    iteration than the fused kernel.  Same return convention as run_stage."""
+    import math
+    from .model_utils_completion import calc_cd_percent, loss_view
+    from .train_utils import rotation, translation
+    dev = src.device
+    P, N, _ = src.shape
+    n = P * K
+    dt = torch.float64 if f64_params else torch.float32
+    p0 = torch.as_tensor(params, dtype=torch.float64).to(dev)
+    leaves = [p0[:, 0:3].to(dt).clone().requires_grad_(True), p0[:, 3:4].to(dt).clone().requires_grad_(True),
+              p0[:, 4:7].to(dt).clone().requires_grad_(True), p0[:, 7:8].to(dt).clone().requires_grad_(True)]
+    opt = torch.optim.Adam(leaves, lr=lr)
+    srck = src.repeat_interleave(K, dim=0)      # houv.py:111-112 replicates the clouds K-fold as well
+    tgtk = tgt.repeat_interleave(K, dim=0)
+    out = None
+    for it in range(n_iters):
+        V, a, c, sc = (l.float() for l in leaves)      # the pose is evaluated in fp32, as in the fused kernel
+        angle = torch.sin(a * math.pi) * math.pi / 8 + math.pi / 8 + angle_base * math.pi / 4
+        R = rotation(angle, V)
+        sigma = torch.sin(sc * math.pi) * 0.125 + 0.125 if trans_mode == 0 else torch.sin(sc * math.pi)
+        T = translation(c, sigma)
+        moved = torch.bmm(srck, R.transpose(1, 2)) + T
+        cds = [calc_cd_percent(moved, tgtk, percent=alpha)]
+        min_1, _ = torch.min(torch.stack(cds[0], dim=1), dim=1)
+        loss = min_1 * 6
+        if use_views:
+            for d in range(3):
+                cds.append(loss_view(moved, tgtk, dim=d))
+                v, _ = torch.min(torch.stack(cds[-1], dim=1), dim=1)
+                loss = loss + v
+        opt.zero_grad()
+        loss.mean().backward()
+        if it == n_iters - 1:
+            out = dict(score=min_1.detach().float(), loss=loss.detach().float(), R=R.detach().float().contiguous(),
+                       T=T.detach().float()[:, 0].contiguous())
+            if want_grad:
+                out["grad"] = torch.cat([l.grad for l in leaves], dim=1).float()
+            if want_cd:
+                cd = torch.zeros((n, 8), dtype=torch.float32, device=dev)
+                for m, (c0, c1) in enumerate(cds):
+                    cd[:, 2 * m], cd[:, 2 * m + 1] = c0.detach(), c1.detach()
+                out["cd"] = cd
+        opt.step()
+    state = torch.zeros((n, 24), dtype=torch.float64, device=dev)
+    state[:, :8] = torch.cat([l.detach() for l in leaves], dim=1).double()
+    state[:, 8:16] = torch.cat([opt.state[l]["exp_avg"] for l in leaves], dim=1).double()
+    state[:, 16:24] = torch.cat([opt.state[l]["exp_avg_sq"] for l in leaves], dim=1).double()
+    return out, state
+
+
 def run_stage(src, tgt, params, K, n_iters, *, angle_base, trans_mode, use_views, f64_params, lr,
               iters_per_launch=None, want_grad=False, want_cd=False, alpha=0.5, pruned=None):
     """Run ``n_iters`` optimisation iterations for P*K hypotheses.  params: float64 [P*K,8] (numpy or tensor).
@@ -90,10 +148,16 @@ def run_stage(src, tgt, params, K, n_iters, *, angle_base, trans_mode, use_views
                            "non-singleton dimension 1")
     dev = src.device
     n = P * K
-    state = torch.zeros((n, 24), dtype=torch.float64, device=dev)
     p = torch.as_tensor(params, dtype=torch.float64)
     if tuple(p.shape) != (n, 8):
         raise ValueError(f"params must be [{n},8]")
+    if max(N, tgt.shape[1]) > FUSED_MAX_POINTS:
+        from . import _lib
+        _lib.require_gpu(src, tgt)
+        return _run_stage_unfused(src, tgt, p, K, n_iters, angle_base=angle_base, trans_mode=trans_mode,
+                                  use_views=use_views, f64_params=f64_params, lr=lr, want_grad=want_grad,
+                                  want_cd=want_cd, alpha=alpha)
+    state = torch.zeros((n, 24), dtype=torch.float64, device=dev)
     state[:, :8] = p.to(dev)
     k_full = int(N * alpha)            # model_utils_completion.py:85-86 with percent = alpha
     k_view = int(N * 1)

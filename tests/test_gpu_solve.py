@@ -189,6 +189,40 @@ def test_end_to_end_64_pairs_vs_reference(golden, dev):
     assert abs((r < 5).mean() - (g["ref_r_err"] < 5).mean()) <= 0.05 and abs(t.mean() - g["ref_t_err"].mean()) <= 3e-3
 
 
+@pytest.mark.parametrize("mode", ["houv", "solve"])
+def test_large_cloud_path_matches_fused_kernel(dev, mode, monkeypatch):
+    """Clouds above 4096 points do not fit the fused kernel's LDS and take the un-fused GPU path (stand-alone HIP
+    Chamfer op + autograd + torch Adam).  Forced onto 600-point clouds it must track the fused kernel: same last
+    forward and same parameters / Adam moments after 4 iterations; then a 4500-point problem runs end to end."""
+    from houv_amd import solver, synthetic
+    P, K, N = 2, 26, 600
+    src, tgt, _ = synthetic.make_pairs(P, N, seed=5)
+    src, tgt = src.to(dev), tgt.to(dev)
+    p0 = solver.houv_init_params(P * K)
+    kw = dict(angle_base=1, trans_mode=0 if mode == "houv" else 1, use_views=(mode == "houv"),
+              f64_params=(mode != "houv"), lr=0.01 if mode == "houv" else 0.1, want_grad=True, want_cd=True)
+    fused, st_f = solver.run_stage(src, tgt, p0, K, 4, **kw)
+    monkeypatch.setattr(solver, "FUSED_MAX_POINTS", 0)
+    unf, st_u = solver.run_stage(src, tgt, p0, K, 4, **kw)
+    monkeypatch.setattr(solver, "FUSED_MAX_POINTS", 4096)
+    tol = 2e-5 if mode == "houv" else 2e-4          # lr 0.1 amplifies fp32 rounding of the first steps
+    for key in ("score", "loss", "R", "T", "cd"):
+        assert torch.allclose(unf[key], fused[key], rtol=0, atol=tol * (5 if key == "loss" else 1)), key
+    g_scale = fused["grad"].abs().max(dim=1, keepdim=True)[0]
+    err = ((unf["grad"] - fused["grad"]).abs() / g_scale).max(dim=1)[0]
+    # the two paths sum in different orders: after a few steps a hypothesis may sit on the other side of an fp32
+    # near-tie of its nearest neighbour (one point's share of the gradient, <= ~3/N each)
+    assert int((err > 2e-4).sum()) <= 4 and float(err.max()) < 12.0 / N, err
+    assert torch.allclose(st_u[:, :8], st_f[:, :8], rtol=0, atol=20 * tol)
+    assert torch.allclose(st_u[:, 8:16], st_f[:, 8:16], rtol=1e-2, atol=1e-7)
+    big_s, big_t, _ = synthetic.make_pairs(1, 4500, seed=6)
+    out, st = solver.run_stage(big_s.to(dev), big_t.to(dev), solver.houv_init_params(26), 26, 2, angle_base=0,
+                               trans_mode=0, use_views=True, f64_params=False, lr=0.01)
+    assert bool(torch.isfinite(out["score"]).all()) and tuple(out["R"].shape) == (26, 3, 3)
+    eye = torch.eye(3, device=dev).expand(26, 3, 3)
+    assert torch.allclose(torch.bmm(out["R"], out["R"].transpose(1, 2)), eye, atol=1e-5)
+
+
 def test_topk_size_out_of_range_is_an_error(dev):
     """topk(k) with k > number of points raises in the reference (model_utils_completion.py:91): M < N with views."""
     from houv_amd import _lib, solver, synthetic
