@@ -11,10 +11,12 @@
 //   BT = false: B is [K,N] row-major (P V of attention)                                  -> C = A B
 //   epilogue  : v = alpha*acc; v = v*scale[n] + shift[n] (eval BatchNorm folded) | v += shift[n] (bias);
 //               v += residual[m,n]; v = max(v,0)
-// Tile 128 x BN x 32, 256 threads = 4 waves (2x2), each wave a 64 x BN/2 block of 32x32 MFMA tiles; LDS tiles are
+// Tile 128 x BN x 32, 512 threads = 8 waves (4x2), each wave a 32 x BN/2 block of 32x32 MFMA tiles (or 256 threads,
+// 2x2 waves of 64 x BN/2); LDS tiles are
 // stored k-major so an MFMA operand fetch is a conflict-free ds_read_b32 (lanes 0-31: 32 consecutive rows at k,
 // lanes 32-63: the same rows at k+1); the next k-tile is prefetched into registers while the current one is
 // multiplied.
+#include <cstdlib>
 #include "../../include/houv_hip.h"
 #include "houv_common.h"
 
@@ -51,15 +53,19 @@ __device__ __forceinline__ float4 load4_guarded(const float* __restrict__ p, int
 // where the MFMA stream dominates; 3 (<= 168 registers): best for K <= 256, where prologue, staging and the epilogue
 // of a workgroup have to hide behind other workgroups (measured: conv 64->128 41.7 -> 48.1, Q K^T 61 -> 72 TFLOP/s,
 // but 4096^3 109.6 -> 102.6).
-template <int BN, bool BT, int WPE>
-__global__ __launch_bounds__(256, WPE) void gemm_f32_kernel(GemmArgs g) {
+// NWM: waves along M (2: 256 threads, each wave 64 x BN/2; 4: 512 threads, each wave 32 x BN/2 -- twice the MFMA
+// streams per workgroup for grids that put only one or two workgroups on a CU).
+template <int BN, bool BT, int WPE, int NWM = 2>
+__global__ __launch_bounds__(NWM * 128, WPE) void gemm_f32_kernel(GemmArgs g) {
+  constexpr int NT = NWM * 128;                        // threads
+  constexpr int MI = BM / (32 * NWM);                  // 32-row MFMA tiles per wave along M
   constexpr int LDA = BM + 1;                         // k-major tiles, +1 breaks the transposing writes' conflicts
   constexpr int LDB = BT ? (BN + 1) : (BN + 4);       // the [K,N] form is written with 16-byte stores
   constexpr int NI = BN / 64;                         // 32-wide MFMA tiles per wave along N
-  constexpr int AREG = BM * BK / 4 / 256;             // float4 per thread per A tile
-  constexpr int BREG = BN * BK / 4 / 256;
+  constexpr int AREG = BM * BK / 4 / NT;              // float4 per thread per A tile
+  constexpr int BREG = BN * BK / 4 / NT;
   constexpr int QK = BK / 4;                          // k-quads per row
-  constexpr int RPI = 256 / QK;                       // rows covered per pass
+  constexpr int RPI = NT / QK;                        // rows covered per pass
   __shared__ float As[BK * LDA];
   __shared__ __attribute__((aligned(16))) float Bs[BK * LDB];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -72,9 +78,9 @@ __global__ __launch_bounds__(256, WPE) void gemm_f32_kernel(GemmArgs g) {
   const bool vecA = ((g.lda & 3) == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0);
   const bool vecB = ((g.ldb & 3) == 0) && ((reinterpret_cast<uintptr_t>(B) & 15) == 0);
 
-  f32x16 acc[2][NI];
+  f32x16 acc[MI][NI];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < MI; ++i)
 #pragma unroll
     for (int j = 0; j < NI; ++j)
 #pragma unroll
@@ -95,7 +101,7 @@ __global__ __launch_bounds__(256, WPE) void gemm_f32_kernel(GemmArgs g) {
         rb[i] = (col < g.N) ? load4_guarded(B + (size_t)col * g.ldb + k, g.K - k, vecB) : make_float4(0.f, 0.f, 0.f, 0.f);
       }
     } else {              // B[k][n]: BK k-rows x BN cols; thread t -> k = t / (BN/4) + (256/(BN/4)) i, n-quad
-      constexpr int QPR = BN / 4, RPP = 256 / QPR;
+      constexpr int QPR = BN / 4, RPP = NT / QPR;
 #pragma unroll
       for (int i = 0; i < BREG; ++i) {
         const int k = k0 + tid / QPR + RPP * i, col = n0 + (tid % QPR) * 4;
@@ -118,7 +124,7 @@ __global__ __launch_bounds__(256, WPE) void gemm_f32_kernel(GemmArgs g) {
         Bs[(k + 2) * LDB + c] = rb[i].z; Bs[(k + 3) * LDB + c] = rb[i].w;
       }
     } else {
-      constexpr int QPR = BN / 4, RPP = 256 / QPR;
+      constexpr int QPR = BN / 4, RPP = NT / QPR;
 #pragma unroll
       for (int i = 0; i < BREG; ++i) {
         const int k = tid / QPR + RPP * i, c = (tid % QPR) * 4;
@@ -136,9 +142,9 @@ __global__ __launch_bounds__(256, WPE) void gemm_f32_kernel(GemmArgs g) {
     const int kh = lane >> 5, rl = lane & 31;
     // operand fragments are double buffered in registers: the ds_reads of k-step s+1 are issued before the MFMAs of
     // k-step s, so their latency hides under 4 x 64 MFMA cycles even when all waves of a SIMD run in lock-step
-    float a[2][2], b[2][NI];
+    float a[2][MI], b[2][NI];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) a[0][i] = As[kh * LDA + wm * 64 + i * 32 + rl];
+    for (int i = 0; i < MI; ++i) a[0][i] = As[kh * LDA + wm * (32 * MI) + i * 32 + rl];
 #pragma unroll
     for (int j = 0; j < NI; ++j) b[0][j] = Bs[kh * LDB + wn * (BN / 2) + j * 32 + rl];
 #pragma unroll
@@ -146,19 +152,19 @@ __global__ __launch_bounds__(256, WPE) void gemm_f32_kernel(GemmArgs g) {
       const int cur = (kk >> 1) & 1, nxt = cur ^ 1;
       if (kk + 2 < BK) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) a[nxt][i] = As[(kk + 2 + kh) * LDA + wm * 64 + i * 32 + rl];
+        for (int i = 0; i < MI; ++i) a[nxt][i] = As[(kk + 2 + kh) * LDA + wm * (32 * MI) + i * 32 + rl];
 #pragma unroll
         for (int j = 0; j < NI; ++j) b[nxt][j] = Bs[(kk + 2 + kh) * LDB + wn * (BN / 2) + j * 32 + rl];
       }
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < NI; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i], b[cur][j], acc[i][j], 0, 0, 0);
       // pin the schedule hipcc would otherwise undo (it sinks the next step's LDS reads below these MFMAs and then waits
       // for them with the matrix pipe idle): first the DS reads of step s+1, then the MFMAs of step s
-      __builtin_amdgcn_sched_group_barrier(0x100, 2 + NI, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, 2 * NI, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, MI + NI, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, MI * NI, 0);
     }
   }
 
@@ -171,10 +177,10 @@ __global__ __launch_bounds__(256, WPE) void gemm_f32_kernel(GemmArgs g) {
     const float sc = g.scale ? g.scale[col] : 1.0f;
     const float sh = g.shift ? g.shift[col] : 0.0f;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < MI; ++i) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const int row = m0 + wm * (32 * MI) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         if (row >= g.M) continue;
         float v = acc[i][j][r] * g.alpha;
         v = v * sc + sh;
@@ -208,16 +214,28 @@ extern "C" int houv_gemm_f32(const float* A, const float* B, float* C, int M, in
   hipStream_t s = (hipStream_t)stream;
   const bool narrow = N <= 64;
   dim3 grid((N + (narrow ? 64 : 128) - 1) / (narrow ? 64 : 128), (M + BM - 1) / BM, outer * inner);
+  // 512-thread workgroups (8 waves, 80 registers, up to 6 waves per SIMD) everywhere: against the 256-thread form
+  // (4 waves, 139-172 registers) short-K shapes gain 15-25 % (conv 64->128: 47 -> 56, Q K^T: 73 -> 90 TFLOP/s) and the
+  // long-K ones are unchanged; HOUV_GEMM_4W=1 selects the 256-thread kernels for comparison.
+  static const bool four_waves = getenv("HOUV_GEMM_4W") != nullptr;
   const bool short_k = K <= 256;
-  if (narrow) {
-    if (trans_b) gemm_f32_kernel<64, true, 3><<<grid, 256, 0, s>>>(g);
-    else gemm_f32_kernel<64, false, 3><<<grid, 256, 0, s>>>(g);
-  } else if (short_k) {
-    if (trans_b) gemm_f32_kernel<128, true, 3><<<grid, 256, 0, s>>>(g);
-    else gemm_f32_kernel<128, false, 3><<<grid, 256, 0, s>>>(g);
+  if (four_waves) {
+    if (narrow) {
+      if (trans_b) gemm_f32_kernel<64, true, 3><<<grid, 256, 0, s>>>(g);
+      else gemm_f32_kernel<64, false, 3><<<grid, 256, 0, s>>>(g);
+    } else if (short_k) {
+      if (trans_b) gemm_f32_kernel<128, true, 3><<<grid, 256, 0, s>>>(g);
+      else gemm_f32_kernel<128, false, 3><<<grid, 256, 0, s>>>(g);
+    } else {
+      if (trans_b) gemm_f32_kernel<128, true, 1><<<grid, 256, 0, s>>>(g);
+      else gemm_f32_kernel<128, false, 1><<<grid, 256, 0, s>>>(g);
+    }
+  } else if (narrow) {
+    if (trans_b) gemm_f32_kernel<64, true, 6, 4><<<grid, 512, 0, s>>>(g);
+    else gemm_f32_kernel<64, false, 6, 4><<<grid, 512, 0, s>>>(g);
   } else {
-    if (trans_b) gemm_f32_kernel<128, true, 1><<<grid, 256, 0, s>>>(g);
-    else gemm_f32_kernel<128, false, 1><<<grid, 256, 0, s>>>(g);
+    if (trans_b) gemm_f32_kernel<128, true, 6, 4><<<grid, 512, 0, s>>>(g);
+    else gemm_f32_kernel<128, false, 6, 4><<<grid, 512, 0, s>>>(g);
   }
   return check_launch("houv_gemm_f32") ? 1 : 0;
 }
