@@ -368,3 +368,29 @@ def test_pruned_search_is_bit_identical_to_brute_force(dev, N, M, views, f64, tm
         for key in ("score", "loss", "R", "T", "grad", "cd"):
             assert torch.equal(out[key], ref[key]), (key, chunk)
         assert torch.equal(st, st_ref), chunk
+
+
+def test_solve_twin_end_to_end_32_pairs_vs_reference(golden, dev):
+    """G14: the REAL reference's ``train_utils.solve`` (test.py:64's path: 500 iterations, lr 0.1, float64 leaves from the
+    harness-seeded global numpy RNG, retry stages) on 32 synthetic 128-pt pairs, K=26.  At lr 0.1 the trajectories are
+    chaotic (registration/README.md:82-91 calls the results non-reproducible), so per-pair answers agree only loosely
+    (measured: 24/32 within 5 deg) and the gate is statistical: mean / median RotE, share solved to < 5 deg, mean transE
+    (measured 26.53 / 4.75 / 53.1 % / 0.085 against the reference's 26.41 / 4.32 / 53.1 % / 0.092)."""
+    from houv_amd.train_utils import rotation_error, solve, translation_error
+    g = golden("g14_twin.npz")
+    K, batch, seed0 = int(g["kernel"]), int(g["batch"]), int(g["seed0"])
+    src, tgt, pose = T(g["src"]), T(g["tgt"]), T(g["pose"])
+    outs = []
+    for i, b in enumerate(range(0, src.shape[0], batch)):
+        np.random.seed(seed0 + i)
+        out = solve(src[b:b + batch].to(dev), tgt[b:b + batch].to(dev), kernel=K, prefix="test")
+        assert not out.is_cuda and tuple(out.shape) == (batch, 4, 4) and bool((out[:, 3] == 0).all())
+        outs.append(out)
+    mine, ref = torch.cat(outs), T(g["ans"])
+    r_m = rotation_error(mine[:, :3, :3], pose[:, :3, :3]).numpy()
+    r_r = rotation_error(ref[:, :3, :3], pose[:, :3, :3]).numpy()
+    t_m = translation_error(mine[:, :3, 3], pose[:, :3, 3]).numpy()
+    t_r = translation_error(ref[:, :3, 3], pose[:, :3, 3]).numpy()
+    assert (np.abs(r_m - r_r) <= 5.0).mean() >= 0.6
+    assert abs(r_m.mean() - r_r.mean()) <= 3.0 and abs(np.median(r_m) - np.median(r_r)) <= 1.5
+    assert abs((r_m < 5).mean() - (r_r < 5).mean()) <= 0.1 and abs(t_m.mean() - t_r.mean()) <= 0.015
