@@ -564,18 +564,26 @@ static int solve_dispatch(const float* src, const float* tgt, int P, int N, int 
       a.ws_valid = 0;
       if (mx <= 256) return launch<256, 1, false, 1>(a, use_views, s);
       if (mx <= 512) return launch<256, 2, false, kOwn2>(a, use_views, s);
+      if (mx <= 768) return launch<256, 3, false, 1>(a, use_views, s);
       if (mx <= 1024) return launch<256, 4, false, kOwn4>(a, use_views, s);
+      if (mx <= 1536) return launch<512, 3, false, 1>(a, use_views, s);
       return launch<512, 4, false, kOwn4>(a, use_views, s);
     }
     if (mx <= 256) return launch<256, 1, true, 1>(a, use_views, s);
     if (mx <= 512) return launch<256, 2, true, kOwn2>(a, use_views, s);
+    if (mx <= 768) return launch<256, 3, true, 1>(a, use_views, s);
     if (mx <= 1024) return launch<256, 4, true, kOwn4>(a, use_views, s);
+    if (mx <= 1536) return launch<512, 3, true, 1>(a, use_views, s);
     return launch<512, 4, true, kOwn4>(a, use_views, s);
   }
   if (mx <= 256) return launch<256, 1, false, 1>(a, use_views, s);
+  // Q = 3 points per lane covers the sizes between the powers of two without idle lanes (768, 1536, 3072)
   if (mx <= 512) return launch<256, 2, false, 1>(a, use_views, s);
+  if (mx <= 768) return launch<256, 3, false, 1>(a, use_views, s);
   if (mx <= 1024) return launch<256, 4, false, 1>(a, use_views, s);
+  if (mx <= 1536) return launch<512, 3, false, 1>(a, use_views, s);
   if (mx <= 2048) return launch<512, 4, false, 1>(a, use_views, s);
+  if (mx <= 3072) return launch<1024, 3, false, 1>(a, use_views, s);
   if (mx <= 4096) return launch<1024, 4, false, 1>(a, use_views, s);
   set_error("%s: clouds larger than 4096 points are not supported (N=%d M=%d)", who, N, M);
   return 0;
