@@ -110,16 +110,25 @@ HOUV_HD inline void pose_backward(const Pose& f, int trans_mode, const float gT[
 // (HOUV module, fp32 parameters: houv.py:54-61,118) or double (`solve` twin keeps float64 leaves:
 // train_utils.py:381-389).  `step` is 1-based.  Mirrors torch's single-tensor formulation:
 //   m += (g-m)(1-b1);  v = v b2 + (1-b2) g g;  p -= (lr/(1-b1^t)) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
-template <typename T>
-HOUV_HD inline void adam_step(T& p, T& m, T& v, T g, int step, double lr, double b1, double b2, double eps) {
-  m = m + (g - m) * (T)(1.0 - b1);
-  v = v * (T)b2 + ((T)(1.0 - b2) * g) * g;
+// The step-dependent scalars (torch computes them in Python doubles): shared by all parameters of a step.
+struct AdamScalars {
+  double step_size, bc2_sqrt;
+};
+HOUV_HD inline AdamScalars adam_scalars(int step, double lr, double b1, double b2) {
   const double bc1 = 1.0 - pow(b1, (double)step);
   const double bc2 = 1.0 - pow(b2, (double)step);
-  const double step_size = lr / bc1;
-  const double bc2_sqrt = sqrt(bc2);
-  const T denom = tsqrt(v) / (T)bc2_sqrt + (T)eps;
-  p = p - (T)step_size * (m / denom);
+  return AdamScalars{lr / bc1, sqrt(bc2)};
+}
+template <typename T>
+HOUV_HD inline void adam_step(T& p, T& m, T& v, T g, const AdamScalars& sc, double b1, double b2, double eps) {
+  m = m + (g - m) * (T)(1.0 - b1);
+  v = v * (T)b2 + ((T)(1.0 - b2) * g) * g;
+  const T denom = tsqrt(v) / (T)sc.bc2_sqrt + (T)eps;
+  p = p - (T)sc.step_size * (m / denom);
+}
+template <typename T>
+HOUV_HD inline void adam_step(T& p, T& m, T& v, T g, int step, double lr, double b1, double b2, double eps) {
+  adam_step<T>(p, m, v, g, adam_scalars(step, lr, b1, b2), b1, b2, eps);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -449,13 +449,14 @@ __global__ __launch_bounds__(BLOCK, 4) void solve_kernel(SolveArgs a) {
             for (int d = 0; d < 2; ++d) a.out_cd[(size_t)inst * 8 + m * 2 + d] = (m < NMET) ? cd[m < NMET ? m : 0][d] : 0.f;
       }
       const int step = a.steps_done + it + 1;
+      const AdamScalars asc = adam_scalars(step, a.lr, a.beta1, a.beta2);   // two double pow() per step, not per parameter
       if (a.f64_params) {
         for (int k = 0; k < 8; ++k)
-          adam_step<double>(sm.state[k], sm.state[8 + k], sm.state[16 + k], (double)g[k], step, a.lr, a.beta1, a.beta2, a.eps);
+          adam_step<double>(sm.state[k], sm.state[8 + k], sm.state[16 + k], (double)g[k], asc, a.beta1, a.beta2, a.eps);
       } else {
         for (int k = 0; k < 8; ++k) {
           float pp = (float)sm.state[k], mm = (float)sm.state[8 + k], vv = (float)sm.state[16 + k];
-          adam_step<float>(pp, mm, vv, g[k], step, a.lr, a.beta1, a.beta2, a.eps);
+          adam_step<float>(pp, mm, vv, g[k], asc, a.beta1, a.beta2, a.eps);
           sm.state[k] = pp; sm.state[8 + k] = mm; sm.state[16 + k] = vv;
         }
       }
