@@ -11,7 +11,6 @@ import logging
 import os
 import sys
 
-import numpy as np
 import torch
 import torch.distributed as dist
 

@@ -5,7 +5,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from .. import ops, solver
+from .. import solver
 from ..model_utils_completion import calc_cd_percent, loss_view
 from ..train_utils import rotation_error, translation_error
 
