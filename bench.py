@@ -281,6 +281,9 @@ def main():
                       "fp32 rate, which is the same 157.3 TFLOP/s for the vector ALUs and for fp32-input MFMA",
         "achieved": achieved, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP32_PEAK_TFLOPS,
         "traffic": None,
+        "traffic_note": "not an HBM-bound kernel; separate rocprofv3 --pmc passes (profiles/r01_pmc_summary.txt) show "
+                        "57 KB fetched + 155 KB written per workgroup-iteration (register-spill traffic, ~6 % of HBM "
+                        "peak) against ~20 MB of algorithmic bytes per launch",
         "launches": len(log), "avg_launch_ms": k_ms / max(len(log), 1),
         # all launches of the process (warm-up included) = what `rocprofv3 --kernel-trace --stats` averages over
         "launches_incl_warmup": len(log_all),
