@@ -30,6 +30,7 @@ _SIGNATURES = {
     "houv_solve_iterate_pruned": (ctypes.c_int, [_c_f, _c_f, _int, _int, _int, _int, _c_f, _int, _int, _int, _int, _int,
                                                  _int, _int, _int, _dbl, _dbl, _dbl, _dbl, _flt, _c_f, _c_f, _c_f, _c_f,
                                                  _c_f, _c_f, _c_f, _int, _int, _c_f]),
+    "houv_solve_variant": (ctypes.c_int, [_int, _int, _int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
     "houv_icp_refine": (ctypes.c_int, [_c_f, _c_f, _int, _int, _int, _c_f, _flt, _int, _flt, _flt, _c_f, _c_f, _c_f, _c_f, _c_f]),
     "houv_knn": (ctypes.c_int, [_c_f, _int, _int, _int, _c_f, _c_f]),
     "houv_edgeconv1": (ctypes.c_int, [_c_f, _c_f, _int, _int, _int, _c_f, _c_f, _c_f, _c_f, _c_f]),
@@ -75,6 +76,13 @@ def load():
         raise HouvHipError(f"libhouv_hip.so ABI {lib.houv_abi_version()} != expected {ABI_VERSION}")
     _lib = lib
     return lib
+
+
+def solve_variant(N, M, pruned=False):
+    """(threads per workgroup, points per lane) of the solve_kernel that serves clouds of N and M points."""
+    b, q = ctypes.c_int(0), ctypes.c_int(0)
+    check(load().houv_solve_variant(int(N), int(M), int(bool(pruned)), ctypes.byref(b), ctypes.byref(q)), "houv_solve_variant")
+    return b.value, q.value
 
 
 def last_error():

@@ -52,6 +52,40 @@ __device__ __forceinline__ int wave_sum_i(int v) {
   return v;
 }
 
+// ---- DPP cross-lane helpers: pure VALU (v_*_dpp), no LDS crossbar round trip like __shfl's ds_bpermute_b32 ------
+// dpp_ctrl encodings (GCN3+/CDNA): row_shr:n = 0x110+n, row_bcast:15 = 0x142, row_bcast:31 = 0x143.
+template <int CTRL, int ROW_MASK = 0xf, int BANK_MASK = 0xf>
+__device__ __forceinline__ float dpp_f(float v) {   // masked-out / out-of-row lanes read 0
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, BANK_MASK, true));
+}
+template <int CTRL, int ROW_MASK = 0xf, int BANK_MASK = 0xf>
+__device__ __forceinline__ int dpp_i(int v) {
+  return __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, BANK_MASK, true);
+}
+
+// Sum over the 64 lanes; the total is valid in LANE 63 ONLY (other lanes hold partial sums).  6 VALU instructions.
+__device__ __forceinline__ float wave_sum_to_lane63(float v) {
+  v += dpp_f<0x111>(v);               // row_shr:1
+  v += dpp_f<0x112>(v);               // row_shr:2
+  v += dpp_f<0x114>(v);               // row_shr:4
+  v += dpp_f<0x118>(v);               // row_shr:8   -> lane 15 of every row of 16 holds the row sum
+  v += dpp_f<0x142, 0xa>(v);          // row_bcast:15 into rows 1 and 3
+  v += dpp_f<0x143, 0xc>(v);          // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave sum
+  return v;
+}
+
+// inclusive prefix sum across the 64 lanes, DPP form (7 VALU instructions)
+__device__ __forceinline__ int wave_incl_scan_dpp(int x) {
+  int v = x + dpp_i<0x111>(x);
+  v += dpp_i<0x112>(x);
+  v += dpp_i<0x113>(x);               // v[i] = x[i-3..i] within the row
+  v += dpp_i<0x114, 0xf, 0xe>(v);     // row_shr:4 into lanes 4..15 of each row
+  v += dpp_i<0x118, 0xf, 0xc>(v);     // row_shr:8 into lanes 8..15
+  v += dpp_i<0x142, 0xa>(v);          // previous row's total into rows 1 and 3
+  v += dpp_i<0x143, 0xc>(v);          // lane 31's total into rows 2 and 3
+  return v;
+}
+
 // inclusive prefix sum across the 64 lanes of a wave
 __device__ __forceinline__ int wave_incl_scan_i(int v) {
   const int lane = threadIdx.x & 63;

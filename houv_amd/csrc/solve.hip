@@ -69,24 +69,28 @@ __device__ unsigned long long g_stamp[16];
 constexpr int kRescanBatch = HOUV_RESCAN_BATCH;
 constexpr int kAccN = 13;      // sum sqrt(d), G[3], (G p^T)[9]
 
+constexpr int kRedStride = 4 * kAccN;   // per-wave partial sums of one direction: [metric][13]
+constexpr int kHistBins = 256;          // 8-bit radix digits
+constexpr int kHistSets = 3;            // rotating histograms: one barrier per radix pass (see select_smallest)
+
 struct Smem {
   float4* tgt;     // [Mpad]
   float4* mov;     // [Npad]
   double* state;   // [24]
   float* pose;     // [12] R row-major, T
   float* acc;      // [8][kAccStride]   slot = metric*2 + dir
-  float* red;      // [NW][kAccStride]
-  unsigned* hist;  // [256]
+  float* red;      // [2 dirs][NW][kRedStride]
+  unsigned* hist;  // [kHistSets][256]
   int* ctl;        // [8 + NW]
-  float4* tbox;    // [2*64] lo/hi boxes of the target's 32-point sub-tiles   (pruned mode)
+  float4* tbox;    // [2*64] lo/hi boxes of the target's 32-point sub-tiles   (pruned mode only)
   float4* mbox;    // [2*64] same for the moved cloud, rebuilt every iteration
 };
 
-__host__ __device__ inline size_t smem_bytes(int N, int M, int block) {
+__host__ __device__ inline size_t smem_bytes(int N, int M, int block, bool prune) {
   const int npad = (N + kSub - 1) / kSub * kSub, mpad = (M + kSub - 1) / kSub * kSub;
   const int nw = block / 64;
-  return (size_t)(npad + mpad) * 16 + 24 * 8 + 12 * 4 + 8 * kAccStride * 4 + (size_t)nw * kAccStride * 4 + 256 * 4 +
-         (8 + nw) * 4 + 64 + 2 * 128 * 16;
+  return (size_t)(npad + mpad) * 16 + 24 * 8 + 12 * 4 + 8 * kAccStride * 4 + (size_t)2 * nw * kRedStride * 4 +
+         kHistSets * kHistBins * 4 + (8 + nw) * 4 + 64 + (prune ? 2 * 128 * 16 : 0);
 }
 
 __device__ inline Smem carve(unsigned char* base, int N, int M, int block) {
@@ -99,54 +103,78 @@ __device__ inline Smem carve(unsigned char* base, int N, int M, int block) {
   s.pose = reinterpret_cast<float*>(s.state + 24);
   s.acc = s.pose + 12;
   s.red = s.acc + 8 * kAccStride;
-  s.hist = reinterpret_cast<unsigned*>(s.red + nw * kAccStride);
-  s.ctl = reinterpret_cast<int*>(s.hist + 256);
+  s.hist = reinterpret_cast<unsigned*>(s.red + 2 * nw * kRedStride);
+  s.ctl = reinterpret_cast<int*>(s.hist + kHistSets * kHistBins);
   s.tbox = reinterpret_cast<float4*>((reinterpret_cast<uintptr_t>(s.ctl + 8 + nw) + 15) & ~(uintptr_t)15);
   s.mbox = s.tbox + 128;
   return s;
 }
 
 // Exact selection of the `ksel` smallest of the BLOCK*Q keys (fp32 bit patterns of non-negative
-// distances; 0xFFFFFFFF marks "not a point").  4-pass 8-bit radix select, LDS histogram.
+// distances; 0xFFFFFFFF marks "not a point").  4-pass 8-bit radix select on LDS histograms.
 // Ties at the threshold are taken in (thread, k) order -- torch.topk leaves tie order unspecified.
+//   * ONE barrier per pass: three histograms rotate (`hrot` = the one this pass fills, all-zero on entry).  While pass p
+//     fills set hrot, every thread also clears set hrot+1, whose last readers (pass p-2) are all past the barrier of
+//     pass p-1; after the barrier EVERY wave scans the 256 bins itself (one ds_read_b128 per lane + a DPP prefix sum),
+//     so no broadcast through LDS and no second barrier is needed.
+//   * pass 0 (sign + 7 exponent bits) sees a handful of distinct digits: plain LDS atomics would serialise 64 lanes
+//     on one address, so the wave counts each digit with a ballot and ONE lane adds the count.
 template <int BLOCK, int Q>
 __device__ __forceinline__ void select_smallest(const unsigned (&key)[Q], int ksel, unsigned* hist, int* ctl,
-                                                bool (&sel)[Q]) {
+                                                bool (&sel)[Q], int& hrot) {
   constexpr int NW = BLOCK / 64;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   unsigned prefix = 0u, mask = 0u;
   int remaining = ksel, neq = 0;
-#pragma unroll 1
+#pragma unroll
   for (int pass = 0; pass < 4; ++pass) {
     const int shift = 24 - 8 * pass;
-    __syncthreads();
-    for (int i = tid; i < 256; i += BLOCK) hist[i] = 0u;
-    __syncthreads();
+    unsigned* h = hist + hrot * kHistBins;
+    const int nxt = (hrot == kHistSets - 1) ? 0 : hrot + 1;
+    for (int i = tid; i < kHistBins; i += BLOCK) hist[nxt * kHistBins + i] = 0u;
+    if (pass == 0) {
 #pragma unroll
-    for (int k = 0; k < Q; ++k)
-      if ((key[k] & mask) == prefix) atomicAdd(&hist[(key[k] >> shift) & 255u], 1u);
-    __syncthreads();
-    if (wave == 0) {
-      const int h0 = (int)hist[4 * lane + 0], h1 = (int)hist[4 * lane + 1], h2 = (int)hist[4 * lane + 2],
-                h3 = (int)hist[4 * lane + 3];
-      const int tot = h0 + h1 + h2 + h3;
-      int c = wave_incl_scan_i(tot) - tot;
-      const int hh[4] = {h0, h1, h2, h3};
-#pragma unroll
-      for (int b = 0; b < 4; ++b) {
-        if (c < remaining && remaining <= c + hh[b]) {
-          ctl[0] = 4 * lane + b;
-          ctl[1] = c;
-          ctl[2] = hh[b];
+      for (int k = 0; k < Q; ++k) {
+        const unsigned digit = key[k] >> 24;
+        unsigned long long todo = __ballot(1);
+        while (todo) {                                           // wave-uniform loop over the distinct digits
+          const int leader = __ffsll((long long)todo) - 1;
+          const unsigned d = (unsigned)__builtin_amdgcn_readlane((int)digit, leader);
+          const unsigned long long m = __ballot(digit == d);
+          if (lane == leader) atomicAdd(&h[d], (unsigned)__popcll(m));
+          todo &= ~m;
         }
-        c += hh[b];
       }
+    } else {
+#pragma unroll
+      for (int k = 0; k < Q; ++k)
+        if ((key[k] & mask) == prefix) atomicAdd(&h[(key[k] >> shift) & 255u], 1u);
     }
     __syncthreads();
-    prefix |= (unsigned)ctl[0] << shift;
-    mask |= 255u << shift;
-    remaining -= ctl[1];
-    neq = ctl[2];
+    {
+      const uint4 hv = *reinterpret_cast<const uint4*>(h + 4 * lane);
+      const int hh[4] = {(int)hv.x, (int)hv.y, (int)hv.z, (int)hv.w};
+      const int tot = hh[0] + hh[1] + hh[2] + hh[3];
+      int c = wave_incl_scan_dpp(tot) - tot;
+      int fbin = 0, fc = 0, fn = 0;
+      bool found = false;
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const bool hit = c < remaining && remaining <= c + hh[b];
+        fbin = hit ? 4 * lane + b : fbin;
+        fc = hit ? c : fc;
+        fn = hit ? hh[b] : fn;
+        found = found || hit;
+        c += hh[b];
+      }
+      const int src_lane = __ffsll((long long)__ballot(found)) - 1;   // exactly one lane holds the bin (1 <= remaining <= total)
+      const int bin = __builtin_amdgcn_readlane(fbin, src_lane);
+      prefix |= (unsigned)bin << shift;
+      mask |= 255u << shift;
+      remaining -= __builtin_amdgcn_readlane(fc, src_lane);
+      neq = __builtin_amdgcn_readlane(fn, src_lane);
+    }
+    hrot = nxt;
   }
   if (neq == remaining) {
 #pragma unroll
@@ -155,7 +183,7 @@ __device__ __forceinline__ void select_smallest(const unsigned (&key)[Q], int ks
     int e = 0;
 #pragma unroll
     for (int k = 0; k < Q; ++k) e += (key[k] == prefix) ? 1 : 0;
-    const int incl = wave_incl_scan_i(e);
+    const int incl = wave_incl_scan_dpp(e);
     __syncthreads();
     if (lane == 63) ctl[8 + wave] = incl;
     __syncthreads();
@@ -170,37 +198,19 @@ __device__ __forceinline__ void select_smallest(const unsigned (&key)[Q], int ks
   }
 }
 
-// Epilogue of one sweep for metric MET.
+// One metric of a sweep's epilogue: exact NN recovery + the 13 sums, per query (nothing is kept per query), then a
+// wave-level DPP reduction whose totals lane 63 parks in red[wave][MET*13 ..].  No barrier in here.
 //   DIR == 1: queries are this lane's moved points (count = N), references the target cloud.
 //   DIR == 0: queries are this lane's target points (count = M), references the moved cloud.
-// Recovers the exact NN, selects the ksel smallest distances, and reduces
 //   S = sum sqrt(d),  G = sum c,  GP = sum c p^T,   c = mask * (moved - target) / sqrt(d),  p = un-moved source point
-// over the selection into acc_out[0..13).
-template <int BLOCK, int Q, int MET, int DIR, int OWN>
+template <int BLOCK, int Q, int NMET, int MET, int DIR, int OWN>
 __device__ __forceinline__ void epilogue_metric(const Smem& sm, const float4* __restrict__ refs, const float (&qx)[Q],
-                                                const float (&qy)[Q], const float (&qz)[Q], const float (&bestm)[Q],
-                                                const int (&btilem)[Q], int count, int ksel, const float (&px)[Q],
-                                                const float (&py)[Q], const float (&pz)[Q], float* acc_out, short* ws HOUV_STAMP_PARAM) {
+                                                const float (&qy)[Q], const float (&qz)[Q], const float (&best)[Q][NMET],
+                                                const int (&btile)[Q][NMET], const bool (&sel)[Q], int count,
+                                                const float (&px)[Q], const float (&py)[Q], const float (&pz)[Q],
+                                                float* red_wave, short* ws) {
   const int tid = threadIdx.x;
   const int rot = tid & (kSub - 1);
-  float nx[Q], ny[Q], nz[Q];
-  unsigned key[Q];
-  bool sel[Q];
-#pragma unroll
-  for (int k = 0; k < Q; ++k) {
-    const float bd = bestm[k];
-    int jn;
-    const float4 nn = recover_nn<MET, kRescanBatch, true>(refs + btilem[k] * kSub, qx[k], qy[k], qz[k], bd, rot, jn);
-    if (ws && pt_index<BLOCK, Q, OWN>(k) < count) ws[pt_index<BLOCK, Q, OWN>(k)] = (short)(btilem[k] * kSub + jn);
-    nx[k] = nn.x; ny[k] = nn.y; nz[k] = nn.z;
-    const bool valid = pt_index<BLOCK, Q, OWN>(k) < count;
-    key[k] = valid ? __float_as_uint(bd) : 0xFFFFFFFFu;
-    sel[k] = valid;
-  }
-  HOUV_STAMP(8);
-  if (ksel < count) select_smallest<BLOCK, Q>(key, ksel, sm.hist, sm.ctl, sel);
-  HOUV_STAMP(9);
-
   float acc[kAccN];
 #pragma unroll
   for (int i = 0; i < kAccN; ++i) acc[i] = 0.f;
@@ -213,17 +223,21 @@ __device__ __forceinline__ void epilogue_metric(const Smem& sm, const float4* __
   }
 #pragma unroll
   for (int k = 0; k < Q; ++k) {
+    const float bd = best[k][MET];
+    int jn;
+    const float4 nn = recover_nn<MET, kRescanBatch, true>(refs + btile[k][MET] * kSub, qx[k], qy[k], qz[k], bd, rot, jn);
+    if (ws && pt_index<BLOCK, Q, OWN>(k) < count) ws[pt_index<BLOCK, Q, OWN>(k)] = (short)(btile[k][MET] * kSub + jn);
     if (sel[k]) {
       // no finite distance (NaN pose from an earlier sqrt'(0)): torch's min/topk/sqrt chain yields NaN, not inf
-      const float s = (bestm[k] < INFINITY) ? sqrtf(bestm[k]) : NAN;
+      const float s = (bd < INFINITY) ? sqrtf(bd) : NAN;
       const float inv = 1.0f / s;   // d == 0 -> inf, and 0*inf = NaN below, as torch's sqrt backward gives
       float dx, dy, dz, sx, sy, sz;
       if constexpr (DIR == 1) {
-        dx = qx[k] - nx[k]; dy = qy[k] - ny[k]; dz = qz[k] - nz[k];
+        dx = qx[k] - nn.x; dy = qy[k] - nn.y; dz = qz[k] - nn.z;
         sx = px[k]; sy = py[k]; sz = pz[k];
       } else {
-        dx = nx[k] - qx[k]; dy = ny[k] - qy[k]; dz = nz[k] - qz[k];
-        const float ux = nx[k] - T[0], uy = ny[k] - T[1], uz = nz[k] - T[2];
+        dx = nn.x - qx[k]; dy = nn.y - qy[k]; dz = nn.z - qz[k];
+        const float ux = nn.x - T[0], uy = nn.y - T[1], uz = nn.z - T[2];
         sx = R[0] * ux + R[3] * uy + R[6] * uz;   // R^T (p' - T)
         sy = R[1] * ux + R[4] * uy + R[7] * uz;
         sz = R[2] * ux + R[5] * uy + R[8] * uz;
@@ -239,36 +253,64 @@ __device__ __forceinline__ void epilogue_metric(const Smem& sm, const float4* __
       acc[10] += cz * sx; acc[11] += cz * sy; acc[12] += cz * sz;
     }
   }
-  HOUV_STAMP(10);
-  block_sum<BLOCK, kAccN>(acc, sm.red, acc_out);
-  HOUV_STAMP(11);
+#pragma unroll
+  for (int i = 0; i < kAccN; ++i) acc[i] = wave_sum_to_lane63(acc[i]);
+  if ((tid & 63) == 63) {
+#pragma unroll
+    for (int i = 0; i < kAccN; ++i) red_wave[MET * kAccN + i] = acc[i];
+  }
 }
 
+// Epilogue of one sweep: top-k selection for the full metric, then per metric the fused rescan + sums; ONE barrier,
+// after which threads 0..NMET*13-1 add the per-wave partial sums (in wave order) into sm.acc[(metric*2+DIR)][0..13).
 template <int BLOCK, int Q, int NMET, int DIR, int OWN>
 __device__ __forceinline__ void epilogue(const Smem& sm, const float4* __restrict__ refs, const float (&qx)[Q],
                                          const float (&qy)[Q], const float (&qz)[Q], const float (&best)[Q][NMET],
                                          const int (&btile)[Q][NMET], int count, int k_full, int k_view,
                                          const float (&px)[Q], const float (&py)[Q], const float (&pz)[Q], short* ws,
-                                         int ws_stride HOUV_STAMP_PARAM) {
-  float bm[Q];
-  int bt[Q];
-#define HOUV_EPI(MET)                                                                                              \
-  {                                                                                                                \
-    _Pragma("unroll") for (int k = 0; k < Q; ++k) {                                                                \
-      bm[k] = best[k][MET];                                                                                        \
-      bt[k] = btile[k][MET];                                                                                       \
-    }                                                                                                              \
-    epilogue_metric<BLOCK, Q, MET, DIR, OWN>(sm, refs, qx, qy, qz, bm, bt, count, (MET == 0) ? k_full : k_view, px, py, \
-                                        pz, sm.acc + (MET * 2 + DIR) * kAccStride,                                 \
-                                        ws ? ws + (size_t)MET * ws_stride : nullptr HOUV_STAMP_ARG);               \
+                                         int ws_stride, int& hrot HOUV_STAMP_PARAM) {
+  constexpr int NW = BLOCK / 64;
+  const int tid = threadIdx.x;
+  bool valid[Q], sel0[Q];
+  unsigned key[Q];
+#pragma unroll
+  for (int k = 0; k < Q; ++k) {
+    valid[k] = pt_index<BLOCK, Q, OWN>(k) < count;
+    key[k] = valid[k] ? __float_as_uint(best[k][0]) : 0xFFFFFFFFu;
+    sel0[k] = valid[k];
   }
-  HOUV_EPI(0)
+  if (k_full < count) select_smallest<BLOCK, Q>(key, k_full, sm.hist, sm.ctl, sel0, hrot);
+  HOUV_STAMP(9);
+  float* red_wave = sm.red + ((size_t)DIR * NW + (tid >> 6)) * kRedStride;
+  epilogue_metric<BLOCK, Q, NMET, 0, DIR, OWN>(sm, refs, qx, qy, qz, best, btile, sel0, count, px, py, pz, red_wave, ws);
   if constexpr (NMET == 4) {
+    // the view terms take all points (k_view == count in every caller; a smaller k_view selects per view metric)
+    bool selv[Q];
+#define HOUV_EPI(MET)                                                                                              \
+    {                                                                                                              \
+      _Pragma("unroll") for (int k = 0; k < Q; ++k) {                                                              \
+        selv[k] = valid[k];                                                                                        \
+        key[k] = valid[k] ? __float_as_uint(best[k][MET]) : 0xFFFFFFFFu;                                           \
+      }                                                                                                            \
+      if (k_view < count) select_smallest<BLOCK, Q>(key, k_view, sm.hist, sm.ctl, selv, hrot);                     \
+      epilogue_metric<BLOCK, Q, NMET, MET, DIR, OWN>(sm, refs, qx, qy, qz, best, btile, selv, count, px, py, pz,   \
+                                                     red_wave, ws ? ws + (size_t)MET * ws_stride : nullptr);       \
+    }
     HOUV_EPI(1)
     HOUV_EPI(2)
     HOUV_EPI(3)
-  }
 #undef HOUV_EPI
+  }
+  HOUV_STAMP(8);
+  __syncthreads();
+  if (tid < NMET * kAccN) {
+    const float* r = sm.red + (size_t)DIR * NW * kRedStride + tid;
+    float a = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) a += r[w * kRedStride];
+    sm.acc[((tid / kAccN) * 2 + DIR) * kAccStride + (tid % kAccN)] = a;
+  }
+  HOUV_STAMP(11);
 }
 
 // PRUNE: the exact pruned search of houv_sweep.h.  OWN: a lane owns Q/OWN chunks of OWN consecutive points (pt_index);
@@ -294,6 +336,8 @@ __global__ __launch_bounds__(BLOCK, 4) void solve_kernel(SolveArgs a) {
   for (int j = tid; j < mpad; j += BLOCK) sm.tgt[j] = (j < M) ? make_float4(tgt[j * 3], tgt[j * 3 + 1], tgt[j * 3 + 2], 0.f) : pad4;
   for (int j = N + tid; j < npad; j += BLOCK) sm.mov[j] = pad4;
   if (tid < 24) sm.state[tid] = a.state[(size_t)inst * 24 + tid];
+  for (int j = tid; j < kHistBins; j += BLOCK) sm.hist[j] = 0u;   // radix-select histogram set 0 (select_smallest rotates)
+  int hrot = 0;
   __syncthreads();
   const int rot = tid & (kSub - 1);
   short* ws_a = nullptr;   // NN of the moved points in the target (direction 1)
@@ -368,7 +412,7 @@ __global__ __launch_bounds__(BLOCK, 4) void solve_kernel(SolveArgs a) {
       }
       HOUV_STAMP(1);
       epilogue<BLOCK, Q, NMET, 1, OWN>(sm, sm.tgt, mx, my, mz, best, btile, N, a.k_full, a.k_view, sx, sy, sz, ws_a,
-                                  a.ws_stride HOUV_STAMP_ARG);
+                                  a.ws_stride, hrot HOUV_STAMP_ARG);
       HOUV_STAMP(2);
     }
     {
@@ -390,7 +434,7 @@ __global__ __launch_bounds__(BLOCK, 4) void solve_kernel(SolveArgs a) {
       }
       HOUV_STAMP(3);
       epilogue<BLOCK, Q, NMET, 0, OWN>(sm, sm.mov, tx, ty, tz, best, btile, M, a.k_full, a.k_view, tx, ty, tz, ws_b,
-                                  a.ws_stride HOUV_STAMP_ARG);
+                                  a.ws_stride, hrot HOUV_STAMP_ARG);
       HOUV_STAMP(4);
     }
     __syncthreads();
@@ -476,7 +520,7 @@ __global__ __launch_bounds__(BLOCK, 4) void solve_kernel(SolveArgs a) {
 
 template <int BLOCK, int Q, bool PRUNE, int OWN>
 int launch(const SolveArgs& a, int use_views, hipStream_t s) {
-  const size_t bytes = smem_bytes(a.N, a.M, BLOCK);
+  const size_t bytes = smem_bytes(a.N, a.M, BLOCK, PRUNE);
   const int grid = a.P * a.K;
   hipError_t e;
   if (use_views) {
@@ -520,6 +564,38 @@ extern "C" int houv_debug_read_stamps(unsigned long long* host_out, int reset) {
 constexpr int kOwn2 = HOUV_PRUNE_OWN < 2 ? HOUV_PRUNE_OWN : 2;
 constexpr int kOwn4 = HOUV_PRUNE_OWN;
 
+// The variant table: which solve_kernel<BLOCK, Q> serves clouds of max(N, M) points.  Q = 3 points per lane covers the
+// sizes between the powers of two without idle lanes (768, 1536, 3072).  tests/test_host_logic.py enumerates this table
+// and fails when a variant has no size that the GPU tests compare with the CPU oracle.
+extern "C" int houv_solve_variant(int N, int M, int pruned, int* block, int* points_per_lane) {
+  using namespace houv;
+  const int mx = N > M ? N : M;
+  if (N <= 0 || M <= 0) {
+    set_error("houv_solve_variant: bad cloud sizes N=%d M=%d", N, M);
+    return 0;
+  }
+  if (pruned && mx > 2048) {
+    set_error("houv_solve_iterate_pruned: clouds of <= 2048 points only (64 sub-tiles per 64-bit visit mask), got N=%d M=%d", N, M);
+    return 0;
+  }
+  if (mx > 4096) {
+    set_error("houv_solve_iterate: clouds larger than 4096 points do not fit in 160 KiB of LDS (N=%d M=%d)", N, M);
+    return 0;
+  }
+  int b, q;
+  if (mx <= 256) { b = 256; q = 1; }
+  else if (mx <= 512) { b = 256; q = 2; }
+  else if (mx <= 768) { b = 256; q = 3; }
+  else if (mx <= 1024) { b = 256; q = 4; }
+  else if (mx <= 1536) { b = 512; q = 3; }
+  else if (mx <= 2048) { b = 512; q = 4; }
+  else if (mx <= 3072) { b = 1024; q = 3; }
+  else { b = 1024; q = 4; }
+  if (block) *block = b;
+  if (points_per_lane) *points_per_lane = q;
+  return 1;
+}
+
 static int solve_dispatch(const float* src, const float* tgt, int P, int N, int M, int K, double* state, int steps_done,
                           int n_iters, int angle_base, int trans_mode, int use_views, int f64_params, int k_full,
                           int k_view, double lr, double beta1, double beta2, double eps, float loss_scale,
@@ -552,41 +628,32 @@ static int solve_dispatch(const float* src, const float* tgt, int P, int N, int 
               ws_stride};
   hipStream_t s = (hipStream_t)stream;
   const int mx = N > M ? N : M;
-  if (smem_bytes(N, M, 1024) > 160 * 1024) {
-    set_error("%s: clouds of %d + %d points do not fit in 160 KiB of LDS", who, N, M);
+  int block = 0, q = 0;
+  if (!houv_solve_variant(N, M, prune ? 1 : 0, &block, &q)) return 0;
+  if (prune && (!nn_ws || ws_stride < mx)) {
+    set_error("%s: pruned mode needs a workspace (ws_stride >= max(N,M))", who);
     return 0;
   }
-  if (prune) {
-    if (mx > 2048 || !nn_ws || ws_stride < mx) {
-      set_error("%s: pruned mode needs clouds of <= 2048 points (64 sub-tiles) and a workspace (ws_stride >= max(N,M))", who);
-      return 0;
-    }
-    if (ws_valid < 0) {   // test aid: the brute-force sweep under the pruned kernel's point ownership / summation order
-      a.ws_valid = 0;
-      if (mx <= 256) return launch<256, 1, false, 1>(a, use_views, s);
-      if (mx <= 512) return launch<256, 2, false, kOwn2>(a, use_views, s);
-      if (mx <= 768) return launch<256, 3, false, 1>(a, use_views, s);
-      if (mx <= 1024) return launch<256, 4, false, kOwn4>(a, use_views, s);
-      if (mx <= 1536) return launch<512, 3, false, 1>(a, use_views, s);
-      return launch<512, 4, false, kOwn4>(a, use_views, s);
-    }
-    if (mx <= 256) return launch<256, 1, true, 1>(a, use_views, s);
-    if (mx <= 512) return launch<256, 2, true, kOwn2>(a, use_views, s);
-    if (mx <= 768) return launch<256, 3, true, 1>(a, use_views, s);
-    if (mx <= 1024) return launch<256, 4, true, kOwn4>(a, use_views, s);
-    if (mx <= 1536) return launch<512, 3, true, 1>(a, use_views, s);
-    return launch<512, 4, true, kOwn4>(a, use_views, s);
+  bool verify = false;
+  if (prune && ws_valid < 0) {   // test aid: the brute-force sweep under the pruned kernel's point ownership / summation order
+    a.ws_valid = 0;
+    verify = true;
   }
-  if (mx <= 256) return launch<256, 1, false, 1>(a, use_views, s);
-  // Q = 3 points per lane covers the sizes between the powers of two without idle lanes (768, 1536, 3072)
-  if (mx <= 512) return launch<256, 2, false, 1>(a, use_views, s);
-  if (mx <= 768) return launch<256, 3, false, 1>(a, use_views, s);
-  if (mx <= 1024) return launch<256, 4, false, 1>(a, use_views, s);
-  if (mx <= 1536) return launch<512, 3, false, 1>(a, use_views, s);
-  if (mx <= 2048) return launch<512, 4, false, 1>(a, use_views, s);
-  if (mx <= 3072) return launch<1024, 3, false, 1>(a, use_views, s);
-  if (mx <= 4096) return launch<1024, 4, false, 1>(a, use_views, s);
-  set_error("%s: clouds larger than 4096 points are not supported (N=%d M=%d)", who, N, M);
+  // one instantiation per row of the variant table (houv_solve_variant), x {views, no views}
+#define HOUV_GO(B_, Q_, OWN_)                                                    \
+  if (block == B_ && q == Q_) {                                                  \
+    if (prune && !verify) return launch<B_, Q_, true, OWN_>(a, use_views, s);    \
+    return launch<B_, Q_, false, OWN_>(a, use_views, s);                         \
+  }
+  if (prune) {
+    HOUV_GO(256, 1, 1) HOUV_GO(256, 2, kOwn2) HOUV_GO(256, 3, 1) HOUV_GO(256, 4, kOwn4)
+    HOUV_GO(512, 3, 1) HOUV_GO(512, 4, kOwn4)
+  } else {
+    HOUV_GO(256, 1, 1) HOUV_GO(256, 2, 1) HOUV_GO(256, 3, 1) HOUV_GO(256, 4, 1)
+    HOUV_GO(512, 3, 1) HOUV_GO(512, 4, 1) HOUV_GO(1024, 3, 1) HOUV_GO(1024, 4, 1)
+  }
+#undef HOUV_GO
+  set_error("%s: no kernel variant <%d,%d>", who, block, q);
   return 0;
 }
 

@@ -111,6 +111,13 @@ int houv_solve_iterate_pruned(const float* src, const float* tgt, int P, int N, 
                               float* out_grad, float* out_cd,
                               int16_t* nn_ws, int ws_valid, int ws_stride, void* stream);
 
+/* Which kernel variant the two entry points above launch for clouds of N and M points (host-only query, no GPU work):
+ * *block = threads per workgroup (256 / 512 / 1024), *points_per_lane = query points a lane owns (1..4).  Returns 0
+ * with houv_last_error() set when no variant serves the size (max(N,M) > 4096; pruned != 0: max(N,M) > 2048).
+ * No counterpart in the reference (its kernel has one fixed launch shape, chamfer3D.cu:142-143); exported so that
+ * the test-suite can prove that every variant is compared with the CPU oracle. */
+int houv_solve_variant(int N, int M, int pruned, int* block, int* points_per_lane);
+
 /* ---------------------------------------------------------------------------------------------
  * Point-to-point ICP refinement, one pair per workgroup (BASELINE configs[3]).
  * Replaces: the per-pair Open3D call of registration/train_ICP.py:137-153

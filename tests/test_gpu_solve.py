@@ -7,6 +7,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 from oracle import houv_ref_cpu as orc  # noqa: E402
+from solve_cases import ORACLE_CASES, PRUNED_CASES, oracle_batch  # noqa: E402
 
 T = torch.tensor
 
@@ -36,14 +37,15 @@ def _oracle_terms(src, tgt, params, base, mode="houv"):
                 R=R.detach().numpy(), T=Tt.detach().numpy()[:, 0])
 
 
-@pytest.mark.parametrize("N,M,base,mode", [(128, 128, 0, "houv"), (200, 200, 2, "houv"), (96, 160, 1, "solve"),
-                                           (300, 300, 3, "solve"), (600, 600, 0, "houv"), (1100, 1100, 1, "houv"),
-                                           (2500, 2500, 2, "houv"), (3000, 2200, 0, "solve")])
+@pytest.mark.parametrize("N,M,base,mode", ORACLE_CASES)
 def test_single_forward_backward_vs_oracle(dev, N, M, base, mode):
     """Per-op rung: the 8 Chamfer terms (1e-5, north_star's Chamfer bar), loss, min_1, R/T and the parameter
-    gradient (1e-4 relative to the largest component) of one forward from identical parameters."""
-    from houv_amd import ops, synthetic
-    P = 30 if max(N, M) <= 1100 else 8          # the float64 [P,N,M] oracle temp is 50 MB per hypothesis at 2500^2
+    gradient (1e-4 relative to the largest component) of one forward from identical parameters.  ORACLE_CASES holds a
+    view-term and a no-view size for EVERY solve_kernel<BLOCK,Q> variant (tests/test_host_logic.py enforces that),
+    including <512,4> at 2048x2048 -- the kernel bench.py times."""
+    from houv_amd import _lib, ops, synthetic
+    P = oracle_batch(N, M)          # the float64 [P,N,M] oracle temp is 134 MB per hypothesis at 4096^2
+    assert _lib.solve_variant(N, M) is not None
     src, tgt, _ = synthetic.make_pairs(P, max(N, M), seed=77)
     src, tgt = src[:, :N].contiguous(), tgt[:, :M].contiguous()
     rng = np.random.default_rng(N + base)
@@ -342,8 +344,7 @@ def test_solve_twin_end_to_end_vs_oracle(golden, dev):
     assert np.all(mine.numpy()[:, 3, :] == 0)
 
 
-@pytest.mark.parametrize("N,M,views,f64,tm", [(2048, 2048, True, False, 0), (700, 700, True, False, 0),
-                                              (1000, 1300, False, True, 1), (200, 200, True, False, 0)])
+@pytest.mark.parametrize("N,M,views,f64,tm", PRUNED_CASES)
 def test_pruned_search_is_bit_identical_to_brute_force(dev, N, M, views, f64, tm):
     """The opt-in pruned search (previous-NN upper bound + sub-tile bounding boxes) must reproduce the brute-force
     kernel BIT FOR BIT on the same clouds: scores, losses, poses, gradients, the 8 Chamfer terms and the optimiser state,

@@ -143,3 +143,26 @@ def test_dataset_layouts_and_pose_samplers():
     assert abs(dataset.rotation_angle_deg(P[:3, :3]) - np.degrees(ang)) < 1e-6
     with pytest.raises(RuntimeError):
         dataset.MVP_RG_rotated("test", args)                 # no h5py / no MVP files here: a clear error, not a crash
+
+
+def test_every_solve_kernel_variant_is_oracle_compared():
+    """The variant table of the fused loop (houv_solve_variant, houv_amd/csrc/solve.hip) enumerated over every cloud
+    size: each solve_kernel<BLOCK, Q, NMET> instantiation must have a size in tests/solve_cases.py at which the GPU
+    tests compare it with the CPU oracle (ORACLE_CASES), and each pruned instantiation a size at which it is compared
+    bit for bit with its brute-force twin (PRUNED_CASES).  Host-only: no GPU work is launched."""
+    from houv_amd import _lib
+    from solve_cases import ORACLE_CASES, PRUNED_CASES
+    table = {_lib.solve_variant(n, n) for n in range(1, 4097)}
+    assert table == {(256, 1), (256, 2), (256, 3), (256, 4), (512, 3), (512, 4), (1024, 3), (1024, 4)}
+    assert _lib.solve_variant(2048, 2048) == (512, 4)            # the kernel bench.py times (BASELINE configs[1])
+    assert _lib.solve_variant(100, 3000) == (1024, 3)            # the larger cloud decides
+    covered = {(_lib.solve_variant(N, M), 4 if mode == "houv" else 1) for N, M, _, mode in ORACLE_CASES}
+    missing = {(v, nmet) for v in table for nmet in (4, 1)} - covered
+    assert not missing, f"solve_kernel variants never compared with the oracle: {sorted(missing)}"
+    ptable = {_lib.solve_variant(n, n, pruned=True) for n in range(1, 2049)}
+    pcovered = {(_lib.solve_variant(N, M, pruned=True), 4 if views else 1) for N, M, views, _, _ in PRUNED_CASES}
+    pmissing = {(v, nmet) for v in ptable for nmet in (4, 1)} - pcovered
+    assert not pmissing, f"pruned solve_kernel variants never compared with brute force: {sorted(pmissing)}"
+    for bad in ((4097, 10, False), (10, 2049, True), (0, 5, False)):
+        with pytest.raises(_lib.HouvHipError):
+            _lib.solve_variant(*bad)
