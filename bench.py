@@ -11,7 +11,10 @@ solves its own batch of the same size (weak scaling; pairs are independent, no d
 exchange the per-pair (R,t) of all timed steps with ONE RCCL all-gather inside the timed region.  Rank 0 prints one JSON line.
 
 Extra objects on the line:
-  roofline      the dominant kernel (houv::solve_kernel), timed live with HIP events on its launch stream
+  roofline      the dominant kernel (houv::solve_kernel, brute-force sweep), timed live with HIP events on its launch stream;
+                VALU-issue bound: `frac` is the share of the chip's VALU issue slots the two sweeps occupy
+  pruned        the same batches through the opt-in EXACT pruned search (houv_solve_iterate_pruned): pairs/s, us per
+                hypothesis-iteration, and whether every transform came out bit-identical to the brute-force run
   chamfer_op    the stand-alone Chamfer op at the same cloud size (BASELINE metric's "Chamfer HBM GB/s" half)
   cpu_baseline  the CPU oracle (oracle/houv_ref_cpu.py, the reference's PyTorch-CPU formulation) on a bounded sample
 """
@@ -31,6 +34,14 @@ sys.path.insert(0, ROOT)
 FP32_PEAK_TFLOPS = 157.3     # MI355X fp32 vector == fp32-input MFMA peak (MI355X_MICROARCH.md, chip-level table)
 HBM_PEAK_GBPS = 8000.0
 FLOP_PER_EVAL = 8            # 3 sub + 1 mul + 2 fma per squared distance
+PEAK_CLOCK_HZ = 2.4e9        # the clock the 157.3 TFLOP/s peak is quoted at: 1024 SIMDs x 64 lanes x 2 flop / 2 clk
+N_SIMD = 1024
+# VALU issue slots (one slot = one full-rate wave64 instruction = 2 clk of a SIMD) the sweep spends per point pair and wave:
+#   4-metric sweep: 3 v_sub + 2 v_mul + 4 v_fma = 9 slots, 2 v_min3 at half rate = 4 slots, sub-tile tracking 0.375 -> 13.375
+#   1-metric sweep: 3 v_sub + 1 v_mul + 2 v_fma = 6 slots, 1/2 v_min3 = 1 slot, tracking 0.094             ->  7.094
+# (scripts/ubench/valu_rate.hip measured the rates: profiles/r01_valu_rate.txt)
+SLOTS_PER_PAIR = {True: 13.375, False: 7.094}
+EXEC_FLOP_PER_PAIR = {True: 13.0, False: 8.0}     # flops the fused sweep really executes per point pair (mins not counted)
 
 
 def parse():
@@ -52,6 +63,7 @@ def parse():
                     help="brute = the brute-force sweep north_star specifies (default, what the roofline is defined on); "
                          "pruned = opt-in exact search (bit-identical outputs on the same clouds, Morton-sorted inputs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pruned", action="store_true", help="skip the `pruned` leg (same batches through the exact pruned search)")
     ap.add_argument("--no-chamfer-op", action="store_true")
     return ap.parse_args()
 
@@ -75,11 +87,62 @@ def cpu_baseline(points, kernel, iters, inst_iters_per_pair):
         n_done += k_s * it_s
     dt = time.time() - t0
     per = dt / n_done
-    return {"value": 1.0 / (per * inst_iters_per_pair), "unit": "pairs/s", "cores": cores, "kind": "port",
+    return {"value": 1.0 / (per * inst_iters_per_pair), "unit": "pairs/s", "cores": cores,
+            "kind": "port (oracle restatement: oracle/houv_ref_cpu.py, pinned bit for bit to the reference's own outputs)",
             "sample": f"{n_done} hypothesis-iterations of oracle.predict_model at {points}x{points} points "
                       f"({dt:.1f} s, {per:.3f} s each), scaled linearly to the {inst_iters_per_pair:.0f} "
                       "hypothesis-iterations per pair the GPU run executed",
             "seconds_per_hypothesis_iteration": per}
+
+
+def pmc_traffic(wg_iters_per_launch, points):
+    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (bench.py cannot run
+    under the profiler itself): profiles/r02_pmc_traffic.json holds FETCH_SIZE / WRITE_SIZE per workgroup-iteration,
+    collected in separate --pmc runs and corrected as MI355X_MICROARCH.md prescribes; scaled to this run's launches."""
+    path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+    if points != 2048 or not os.path.exists(path):
+        return None, "no PMC pass for this configuration (profiles/r02_pmc_traffic.json covers 2048-point clouds)"
+    with open(path) as f:
+        t = json.load(f)
+    per = t["fetch_bytes_per_wg_iter"] + t["write_bytes_per_wg_iter"]
+    return per * wg_iters_per_launch, t["note"]
+
+
+def pruned_leg(args, dev, batches, timed, brute_answers, net):
+    """The same timed batches through the opt-in exact pruned search; repeated until >= 5 steps are timed."""
+    from houv_amd import solver
+    from houv_amd.models.houv import predict_model
+    if args.points > 2048:
+        return {"skipped": "the pruned search serves clouds of <= 2048 points (64-bit visit masks)"}
+
+    def solve(s, t):
+        ans, _, _ = solver.best_of_k_with_retry(
+            lambda ss, tt, base: predict_model(net, ss, tt, kernel=args.kernel, num_epochs=args.iters, angle_base=base), s, t)
+        return ans
+    old, solver.PRUNED = solver.PRUNED, True
+    try:
+        solver.LAUNCH_LOG = []
+        identical = all(bool(torch.equal(solve(batches[b][0], batches[b][1]), brute_answers[b])) for b in timed)   # + warm-up
+        reps = max(1, -(-5 // len(timed)))
+        solver.LAUNCH_LOG = []
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            for b in timed:
+                solve(batches[b][0], batches[b][1])
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        log, solver.LAUNCH_LOG = solver.LAUNCH_LOG, None
+    finally:
+        solver.PRUNED = old
+    k_ms = sum(e0.elapsed_time(e1) for e0, e1, *_ in log)
+    inst_iters = sum(n * it for _, _, n, it, *_ in log)
+    steps = reps * len(timed)
+    return {"solver": "houv_solve_iterate_pruned (exact: previous-NN upper bound + sub-tile bounding boxes)",
+            "value": args.pairs * steps / dt, "unit": "pairs/s", "steps": steps, "ms_per_step": dt * 1e3 / steps,
+            "us_per_hypothesis_iteration": k_ms * 1e3 / max(inst_iters, 1),
+            "bit_identical_to_brute_force": identical,
+            "compared": "ans[P,4,4] of every timed batch, torch.equal against the brute-force run of the same batch"}
 
 
 def chamfer_op_probe(dev, points):
@@ -202,7 +265,10 @@ def main():
     batches = []
     for b in range(n_batches):
         s, t, pose = synthetic.make_pairs(P, args.points, seed=2021, first_id=(b * world + rank) * P)
-        batches.append((s.to(dev), t.to(dev), pose.to(dev)))
+        # the order of the points of a cloud carries no meaning: sort both clouds along a Morton curve once, outside
+        # the timed region, so that the brute-force run and the `pruned` leg (which needs spatially compact
+        # sub-tiles) see IDENTICAL inputs and their outputs can be compared bit for bit
+        batches.append((solver.morton_sort(s.to(dev)), solver.morton_sort(t.to(dev)), pose.to(dev)))
     net = HOUV(P * args.kernel, 0).to(dev)
     results = []
 
@@ -270,37 +336,45 @@ def main():
     t_err = translation_error(mine[:, :3, 3], pose[:, :3, 3])
 
     # ---- dominant kernel: live HIP-event timing on the launch stream ----
+    from houv_amd import _lib
     k_ms = sum(e0.elapsed_time(e1) for e0, e1, *_ in log)
     inst_iters = sum(n * it for _, _, n, it, *_ in log)
-    evals = sum(n * it * 8.0 * N * M for _, _, n, it, N, M, v in log)        # 4 metrics x 2 directions x N x M
-    flops = evals * FLOP_PER_EVAL
-    achieved = flops / (k_ms * 1e-3) / 1e12
+    evals = sum(n * it * (8.0 if v else 2.0) * N * M for _, _, n, it, N, M, v in log)   # (4 metrics | 1) x 2 directions x N x M
+    flops_alg = evals * FLOP_PER_EVAL
+    slots = sum(n * it * 2.0 * N * M / 64.0 * SLOTS_PER_PAIR[bool(v)] for _, _, n, it, N, M, v in log)   # wave-level issue slots
+    flops_exec = sum(n * it * 2.0 * N * M * EXEC_FLOP_PER_PAIR[bool(v)] for _, _, n, it, N, M, v in log)
+    secs = k_ms * 1e-3
+    frac_valu = slots / (secs * PEAK_CLOCK_HZ / 2.0 * N_SIMD)          # a SIMD offers one issue slot per 2 clk
+    # the kernel the log's launches ran: template arguments from the variant table and the launch's view flag
+    kinds = sorted({(_lib.solve_variant(N, M, args.solver == "pruned"), 4 if v else 1) for *_, N, M, v in log})
+    kname = ", ".join("houv::solve_kernel<%d, %d, %d, %s, 1>" % (b, q, nm, "true" if args.solver == "pruned" else "false")
+                      for (b, q), nm in kinds)
+    wg_iters_per_launch = inst_iters / max(len(log), 1)
+    traffic, traffic_note = pmc_traffic(wg_iters_per_launch, args.points)
     roofline = {
-        "kernel": "houv::solve_kernel<512, 4, 4, %s, 1>" % ("true" if args.solver == "pruned" else "false"), "bound": "mfma",
-        "bound_note": "compute bound on the fp32 VALU issue rate; the kernel issues no MFMA -- `peak` is MI355X's dense "
-                      "fp32 rate, which is the same 157.3 TFLOP/s for the vector ALUs and for fp32-input MFMA",
-        "achieved": achieved, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP32_PEAK_TFLOPS,
-        "traffic": None,
-        "traffic_note": "not an HBM-bound kernel; separate rocprofv3 --pmc passes (profiles/r01_pmc_summary.txt) show "
-                        "57 KB fetched + 155 KB written per workgroup-iteration (register-spill traffic, ~6 % of HBM "
-                        "peak) against ~20 MB of algorithmic bytes per launch",
+        "kernel": kname, "bound": "valu",
+        "bound_note": "compute bound on the fp32 VALU ISSUE rate (no MFMA, ~0 algorithmic HBM bytes: 2048^2 brute force has "
+                      "~820 flop/byte). `achieved` counts every VALU issue slot the two sweeps need as one FMA slot "
+                      "(64 lanes x 2 flop; half-rate v_min3 = 2 slots), so achieved/peak = the share of the chip's "
+                      "issue slots at the 2.4 GHz peak clock that the sweeps occupy; the chip sustains ~2.2 GHz under "
+                      "this load, i.e. the same work fills ~9 % more of the slots actually offered",
+        "achieved": frac_valu * FP32_PEAK_TFLOPS, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": frac_valu,
+        "executed_tflops": flops_exec / secs / 1e12,                    # fp32 flops really executed (13 per 4-metric point pair)
+        "achieved_algorithmic": flops_alg / secs / 1e12,                # SURVEY 8(d) accounting: 8 separate 8-flop sweeps
+        "frac_algorithmic": flops_alg / secs / 1e12 / FP32_PEAK_TFLOPS,
+        "frac_algorithmic_note": "credits the fused 4-metric sweep as four separate 8-flop evaluations (SURVEY.md 8d); it "
+                                 "says how much work a non-fused formulation would have needed, not how busy the ALUs are",
+        "traffic": traffic, "traffic_note": traffic_note,
         "launches": len(log), "avg_launch_ms": k_ms / max(len(log), 1),
         # all launches of the process (warm-up included) = what `rocprofv3 --kernel-trace --stats` averages over
         "launches_incl_warmup": len(log_all),
         "avg_launch_ms_incl_warmup": sum(e0.elapsed_time(e1) for e0, e1, *_ in log_all) / max(len(log_all), 1),
         "us_per_hypothesis_iteration": k_ms * 1e3 / max(inst_iters, 1),
-        "kernel_time_share": k_ms * 1e-3 / dt,
-        "definition": "algorithmic flops = hypothesis-iterations x 8 sweeps x N*M x 8 flop (SURVEY.md 8d); the fused "
-                      "4-metric sweep executes 11 VALU instructions per point pair instead of 4x7, see DESIGN.md",
-        # physical view: VALU pipe cycles the two sweeps need per 4-metric point pair and wave = 9 full-rate ops x 2 clk
-        # + 2 v_min3 x 4 clk (half rate, scripts/ubench/valu_rate.hip) + 0.75 clk of sub-tile tracking = 26.75 clk,
-        # over the SIMD-cycles available at the 2.4 GHz peak clock (the chip holds ~2.3 GHz under this load)
-        "valu_pipe_frac_sweeps": (inst_iters * 2.0 * args.points * args.points / 64 * 26.75) /
-                                 (k_ms * 1e-3 * 2.4e9 * 1024),
+        "kernel_time_share": secs / dt,
     }
     if args.solver == "pruned":
-        roofline["pruned_note"] = ("opt-in exact pruned search: `achieved` still counts the brute-force sweep's flops, so "
-                                   "frac > 1 only says that evaluations were provably skipped; it is not a roofline claim")
+        roofline["pruned_note"] = ("--solver pruned: `achieved` still prices the brute-force sweep's issue slots, so frac > 1 "
+                                   "only says that evaluations were provably skipped; it is not a roofline claim")
     out = {
         "metric": "registration pairs/sec (2048-pt partial pairs)", "value": n_total * args.steps / dt,
         "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -319,6 +393,10 @@ def main():
         "roofline": roofline,
     }
     if rank == 0 and world == 1:
+        if args.solver == "brute" and not args.no_pruned and not args.icp:
+            timed = [b for b, _ in results]
+            out["pruned"] = pruned_leg(args, dev, batches, timed, {b: a for b, a in results}, net)
+            out["pruned"]["speedup_over_brute_force"] = out["pruned"]["value"] / out["value"]
         if not args.no_chamfer_op:
             out["chamfer_op"] = chamfer_op_probe(dev, args.points)
         if not args.no_cpu_baseline:

@@ -1,4 +1,4 @@
-"""Multi-GPU sharding of registration pairs: one process per GPU, contiguous pair ranges, local solve, and ONE
+"""Multi-GPU sharding of registration pairs: one process per GPU, interleaved (or contiguous) pair shards, local solve, and ONE
 all-gather of the per-pair (R, t) -- 12 floats per pair -- over RCCL/xGMI (torch.distributed backend "nccl" is
 RCCL on ROCm; "gloo" is used by the CPU tests).  Replaces the reference's 4 shell processes + ``{l}_{r}.npy`` files
 + ``sleep 600`` + ``--combine`` (registration/run_test.sh:6-23, test_mult.py:70-81, dataset.py:369-372).
@@ -16,9 +16,28 @@ def shard_range(n_pairs, rank, world_size):
     return l, min(l + per, n_pairs)
 
 
-def gather_transforms(ans_local, n_pairs, group=None):
-    """ans_local [n_local,4,4] (this rank's contiguous shard) -> [n_pairs,4,4] on every rank, by a single
-    all_gather of a [per,12] fp32 block per rank (rows beyond a short last shard are padding)."""
+# How solve_sharded deals pairs to ranks.  Stragglers can only come from the data-dependent retry stages (a pair whose
+# base-0 score is > 0.030 costs 4x), and hard pairs cluster in pair order: on 2000 synthetic MVP-shaped pairs split 8
+# ways, contiguous shards carried 4..17 retried pairs each (predicted efficiency mean/max = 0.93 by work), interleaved
+# ones 5..12 (0.98) -- profiles/r02_load_balance.json.  Interleaving is therefore the default; "contiguous" keeps the
+# reference's -l/-r semantics.
+DEFAULT_SHARDING = "interleaved"
+
+
+def shard_indices(n_pairs, rank, world_size, mode=None):
+    """Pair indices of this rank: ``rank, rank + W, rank + 2W, ...`` (interleaved) or the contiguous shard_range."""
+    mode = mode or DEFAULT_SHARDING
+    if mode == "interleaved":
+        return torch.arange(rank, n_pairs, world_size) if rank < n_pairs else torch.zeros(0, dtype=torch.int64)
+    if mode == "contiguous":
+        l, r = shard_range(n_pairs, rank, world_size)
+        return torch.arange(l, r)
+    raise ValueError("sharding mode must be 'interleaved' or 'contiguous'")
+
+
+def gather_transforms(ans_local, n_pairs, group=None, mode="contiguous"):
+    """ans_local [n_local,4,4] (this rank's shard, in shard_indices order) -> [n_pairs,4,4] in pair order on every rank,
+    by a single all_gather of a [per,12] fp32 block per rank (rows beyond a short shard are padding)."""
     if not (dist.is_available() and dist.is_initialized()):
         return ans_local
     world = dist.get_world_size(group)
@@ -30,6 +49,8 @@ def gather_transforms(ans_local, n_pairs, group=None):
         block[:n_local] = ans_local[:, :3, :].reshape(n_local, 12)      # R|t rows; row 3 is all-zero by construction
     out = torch.empty((world * per, 12), dtype=torch.float32, device=dev)
     dist.all_gather_into_tensor(out, block, group=group) if dev.type == "cuda" else _gather_cpu(out, block, world, group)
+    if mode == "interleaved":          # row j of rank r is pair r + j*W: [W, per] -> [per, W] puts them in pair order
+        out = out.reshape(world, per, 12).transpose(0, 1).reshape(world * per, 12)
     full = torch.zeros((n_pairs, 4, 4), dtype=torch.float32, device=dev)
     full[:, :3, :] = out[:n_pairs].reshape(n_pairs, 3, 4)
     return full
@@ -41,17 +62,18 @@ def _gather_cpu(out, block, world, group):
     out.copy_(torch.cat(parts, 0))
 
 
-def solve_sharded(solve_fn, src, tgt, group=None):
+def solve_sharded(solve_fn, src, tgt, group=None, mode=None):
     """Run ``solve_fn(src_shard, tgt_shard) -> ans[n,4,4]`` on this rank's shard of the pair list and gather the
-    transforms of all shards.  ``src``/``tgt`` hold ALL pairs (or anything sliceable by [l:r])."""
+    transforms of all shards, in pair order.  ``src``/``tgt`` hold ALL pairs (anything indexable by an index tensor)."""
+    mode = mode or DEFAULT_SHARDING
     n = src.shape[0]
     if dist.is_available() and dist.is_initialized():
         rank, world = dist.get_rank(group), dist.get_world_size(group)
     else:
         rank, world = 0, 1
-    l, r = shard_range(n, rank, world)
-    if r > l:
-        ans = solve_fn(src[l:r], tgt[l:r])
+    idx = shard_indices(n, rank, world, mode)
+    if idx.numel() > 0:
+        ans = solve_fn(src[idx], tgt[idx])
     else:
         ans = torch.zeros((0, 4, 4), dtype=torch.float32, device=src.device)
-    return gather_transforms(ans, n, group)
+    return gather_transforms(ans, n, group, mode)

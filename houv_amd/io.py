@@ -58,20 +58,49 @@ def load_results(path):
 
 
 MVP_KEYS = ("src", "tgt", "complete", "transforms", "rotated_src", "rotated_tgt", "pose_src", "pose_tgt", "rot_level",
-            "match_level", "match_id", "cat_labels")
+            "match_level", "cat_labels")
+MVP_FILES = {"train": "MVP_Train_RG.h5", "val": "MVP_Test_RG.h5", "test": "MVP_ExtraTest_RG.h5"}   # dataset.py:194-199
 
 
-def load_mvp_rg(path, l=None, r=None):
-    """MVP_*_RG.h5 reader (registration/dataset.py:205-238, :369-372): returns dict(src, tgt[, transforms, ...]) of the
-    arrays present, optionally sliced [l:r] like MVP_RG_rotated_bound."""
+def open_h5(path):
+    """h5py.File when h5py is installed, else the dependency-free reader (same mapping-style access either way)."""
+    return h5py.File(path, "r") if h5py is not None else hdf5_min.H5File(path)
+
+
+def mvp_path(prefix, args=None):
+    """The reference opens ./data/MVP_*_RG.h5 relative to the working directory (dataset.py:194-199); an optional
+    ``data_dir`` config key (not in the reference's yaml) points elsewhere."""
+    base = getattr(args, "data_dir", None) if args is not None else None
+    return os.path.join(base or "./data", MVP_FILES[prefix])
+
+
+def _is_group(node):
+    return hasattr(node, "keys") and not hasattr(node, "shape")
+
+
+def load_mvp_rg(path, l=None, r=None, keys=MVP_KEYS, match_id=False):
+    """MVP_*_RG.h5 reader (registration/dataset.py:205-238, :369-402): dict of the arrays present among ``keys``, sliced
+    [l:r] along the pair axis like MVP_RG_rotated_bound.  ``match_id`` is a GROUP holding one ragged int dataset per pair,
+    named "0".."n-1" (dataset.py:211-215); with ``match_id=True`` it is returned as a list with one array per pair of
+    the shard (HOUV never reads it; the reference's bound class slices INSIDE each child, :377-379, which is of no use
+    to anybody -- the per-pair lists of the shard are what a caller can want)."""
     if not os.path.exists(path):
         raise RuntimeError("%s not found: the MVP registration files are not shipped; use houv_amd.synthetic / "
                            "dataset.SyntheticRG for MVP-shaped pairs" % path)
     out = {}
-    opener = (lambda p: h5py.File(p, "r")) if h5py is not None else hdf5_min.H5File
-    with opener(path) as f:
-        for k in MVP_KEYS:
+    with open_h5(path) as f:
+        for k in keys:
             if k in f:
                 a = f[k]
-                out[k] = np.array(a[l:r] if (l is not None or r is not None) else a)
+                if _is_group(a):
+                    continue
+                out[k] = np.array(a[l:r] if (l is not None or r is not None) else a[:])
+        if match_id and "match_id" in f:
+            node = f["match_id"]
+            if _is_group(node):
+                n = len(node.keys())
+                lo, hi, _ = slice(l, r).indices(n)
+                out["match_id"] = [np.array(node[str(i)][:]) for i in range(lo, hi)]
+            else:                       # a plain [n, ...] dataset (not what MVP ships, but harmless to serve)
+                out["match_id"] = list(np.array(node[l:r] if (l is not None or r is not None) else node[:]))
     return out

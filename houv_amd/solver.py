@@ -70,7 +70,7 @@ def morton_sort(cloud):
         x = (x | (x << 2)) & 0x09249249
         return x
     code = spread(q[..., 0]) | (spread(q[..., 1]) << 1) | (spread(q[..., 2]) << 2)
-    order = torch.argsort(code, dim=1)
+    order = torch.argsort(code, dim=1, stable=True)     # stable: sorting a sorted cloud again is the identity
     return torch.gather(cloud, 1, order.unsqueeze(2).expand(-1, -1, 3)).contiguous()
 
 
@@ -116,7 +116,8 @@ def _run_stage_unfused(src, tgt, params, K, n_iters, *, angle_base, trans_mode, 
         loss.mean().backward()
         if it == n_iters - 1:
             out = dict(score=min_1.detach().float(), loss=loss.detach().float(), R=R.detach().float().contiguous(),
-                       T=T.detach().float()[:, 0].contiguous())
+                       T=T.detach().float()[:, 0].contiguous(),
+                       last_params=torch.cat([l.detach() for l in leaves], dim=1).double())
             if want_grad:
                 out["grad"] = torch.cat([l.grad for l in leaves], dim=1).float()
             if want_cd:
@@ -133,9 +134,11 @@ def _run_stage_unfused(src, tgt, params, K, n_iters, *, angle_base, trans_mode, 
 
 
 def run_stage(src, tgt, params, K, n_iters, *, angle_base, trans_mode, use_views, f64_params, lr,
-              iters_per_launch=None, want_grad=False, want_cd=False, alpha=0.5, pruned=None):
+              iters_per_launch=None, want_grad=False, want_cd=False, alpha=0.5, pruned=None, want_last_params=False):
     """Run ``n_iters`` optimisation iterations for P*K hypotheses.  params: float64 [P*K,8] (numpy or tensor).
-    Returns (out dict of the last forward, state tensor [P*K,24] fp64 after n_iters Adam steps)."""
+    Returns (out dict of the last forward, state tensor [P*K,24] fp64 after n_iters Adam steps).
+    ``want_last_params``: also return, as out["last_params"] (fp64 [P*K,8]), the parameters the LAST forward read, i.e.
+    before the final Adam step (the last launch is then exactly one iteration; chunking is bit-neutral)."""
     if n_iters < 1:
         raise ValueError("num_epochs must be >= 1 (the reference reads the last iteration's outputs)")
     src = src.contiguous().float()
@@ -168,8 +171,14 @@ def run_stage(src, tgt, params, K, n_iters, *, angle_base, trans_mode, use_views
         src, tgt = morton_sort(src), morton_sort(tgt)
         nn_ws = torch.empty((n, 2, 4, max(N, tgt.shape[1])), dtype=torch.int16, device=dev)
     done, out = 0, None
+    last_params = None
     while done < n_iters:
         it = min(step, n_iters - done)
+        if want_last_params:
+            if done == n_iters - 1:
+                last_params = state[:, :8].clone()
+            else:
+                it = min(it, n_iters - 1 - done)
         last = done + it == n_iters
         if LAUNCH_LOG is not None:
             ev0 = torch.cuda.Event(enable_timing=True)
@@ -184,6 +193,8 @@ def run_stage(src, tgt, params, K, n_iters, *, angle_base, trans_mode, use_views
             ev1.record(torch.cuda.current_stream(dev))
             LAUNCH_LOG.append((ev0, ev1, n, it, N, tgt.shape[1], bool(use_views)))
         done += it
+    if want_last_params:
+        out["last_params"] = last_params
     return out, state
 
 

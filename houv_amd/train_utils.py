@@ -71,9 +71,10 @@ def getPredict_angle(src, src_rotated, pose=None, src_ori=None, tgt_ori=None, an
     n = B * kernel
     params = solver.solve_twin_init_params(n)
     out, state = solver.run_stage(src, src_rotated, params, kernel, num_epochs, angle_base=angle_base, trans_mode=1,
-                                  use_views=False, f64_params=True, lr=0.1)
+                                  use_views=False, f64_params=True, lr=0.1, want_last_params=True)
     pi = torch.acos(torch.zeros(1)).item() * 2
-    tran_s = torch.sin(state[:, 7:8].float() * pi) * 1
+    # tran_s of the LAST forward (train_utils.py:404,456), i.e. from the parameters before the final optimizer.step()
+    tran_s = torch.sin(out["last_params"][:, 7:8].float() * pi) * 1
     return (out["score"].reshape(B, kernel), out["R"].reshape(B, kernel, 3, 3), out["T"].reshape(B, kernel, 3), tran_s)
 
 

@@ -18,6 +18,17 @@ def pytest_configure(config):
     # several times slower than a small one
     import torch
     torch.set_num_threads(max(1, min(8, os.cpu_count() or 1)))
+    # Multi-process GPU tests (tests/test_gpu_distributed.py) take their ranks from a fork SERVER that is started here,
+    # before anything in this process has touched the GPU: its children are forked from a GPU-clean process and
+    # initialise HIP themselves.  (Spawning -- fork + exec -- out of a process that already holds the GPU is what the
+    # GPU boxes forbid.)
+    import multiprocessing as mp
+    try:
+        mp.get_context("forkserver")
+        from multiprocessing import forkserver
+        forkserver.ensure_running()
+    except Exception as e:  # pragma: no cover - platform without forkserver
+        print("forkserver unavailable:", e)
 
 
 @pytest.fixture(scope="session")

@@ -8,7 +8,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 
-def _worker(rank, world, port, n_pairs, q):
+def _worker(rank, world, port, n_pairs, q, mode):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from houv_amd import distributed as hd
@@ -22,27 +22,30 @@ def _worker(rank, world, port, n_pairs, q):
         ans[:, :3, 3] = s[:, 0, :]
         return ans
 
-    full = hd.solve_sharded(fake_solve, src, src)
-    q.put((rank, hd.shard_range(n_pairs, rank, world), full.numpy()))
+    full = hd.solve_sharded(fake_solve, src, src, mode=mode)
+    q.put((rank, hd.shard_indices(n_pairs, rank, world, mode).tolist(), full.numpy()))
     dist.barrier()
     dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("mode", ["interleaved", "contiguous"])
 @pytest.mark.parametrize("n_pairs", [8, 7, 1])
-def test_shard_and_allgather_world2(n_pairs):
+def test_shard_and_allgather_world2(n_pairs, mode):
     from houv_amd import distributed as hd
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os.getpid() % 2000) + n_pairs
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_pairs, q)) for r in range(2)]
+    port = 29500 + (os.getpid() % 2000) + n_pairs + (20 if mode == 'contiguous' else 0)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_pairs, q, mode)) for r in range(2)]
     for p in procs:
         p.start()
     got = [q.get(timeout=120) for _ in procs]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    ranges = sorted(g[1] for g in got)
-    assert ranges[0][0] == 0 and ranges[-1][1] == n_pairs and ranges[0][1] == ranges[1][0]     # contiguous cover
+    assert sorted(got[0][1] + got[1][1]) == list(range(n_pairs))                               # every pair exactly once
+    if mode == "contiguous":
+        ranges = sorted((g[1][0], g[1][-1] + 1) if g[1] else (n_pairs, n_pairs) for g in got)
+        assert ranges[0][0] == 0 and ranges[-1][1] == n_pairs and ranges[0][1] == ranges[1][0]
     want = np.zeros((n_pairs, 4, 4), np.float32)
     for i in range(n_pairs):
         want[i, :3, :3] = np.eye(3) * (1 + i)
@@ -56,3 +59,6 @@ def test_shard_range_matches_reference_slices():
     assert [shard_range(2000, r, 4) for r in range(4)] == [(0, 500), (500, 1000), (1000, 1500), (1500, 2000)]   # run_test.sh:6
     assert [shard_range(1200, r, 8) for r in range(8)][-1] == (1050, 1200)
     assert shard_range(3, 7, 8) == (3, 3)
+    from houv_amd.distributed import shard_indices
+    assert shard_indices(10, 1, 4).tolist() == [1, 5, 9] and shard_indices(10, 3, 4, "contiguous").tolist() == [9]
+    assert shard_indices(2, 3, 4).tolist() == []

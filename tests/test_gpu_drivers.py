@@ -1,4 +1,6 @@
-"""GPU smoke of the driver mirrors (train_HOUV.py / test_mult.py flows) on tiny synthetic workloads."""
+"""GPU runs of the driver mirrors (train_HOUV.py / test.py / test_mult*.py flows) from the miniature MVP files
+(tests/golden/mvp_mini, written by libhdf5) -- BASELINE configs[2] in single-GPU miniature: file -> dataset -> shards ->
+solve -> {l}_{r}.npy -> --combine -> results.h5 -> re-read, equal to a direct ``solve`` on the same arrays."""
 import os
 
 import numpy as np
@@ -8,26 +10,61 @@ import torch
 pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+MINI = os.path.join(ROOT, "tests", "golden", "mvp_mini")
 
 
-def test_train_houv_driver(tmp_path, monkeypatch):
+def _cfg(tmp_path, bs, data_dir=MINI, points=128):
+    cfg = tmp_path / "houv.yaml"
+    cfg.write_text(f"batch_size: {bs}\nworkers: 0\nmodel_name: houv\nload_model: null\nwork_dir: {tmp_path}/log/\nflag: t\n"
+                   f"manual_seed: 2021\nnum_points: {points}\nbenchmark: mvp\nkernel: 32\nlr: 0.01\ndata_dir: {data_dir}\n")
+    return str(cfg)
+
+
+def _direct_solve(src, tgt, bs, K, iters, seed=2021):
+    """What a driver process does with its pairs: seed the global numpy RNG once (test_mult_modelnet.py:84-92), then
+    ``solve`` batch after batch."""
+    from houv_amd.train_utils import solve
+    dev = torch.device("cuda:0")
+    np.random.seed(seed)
+    out = [solve(torch.from_numpy(src[b:b + bs]).to(dev), torch.from_numpy(tgt[b:b + bs]).to(dev), prefix='test',
+                 kernel=K, _iters=iters).numpy() for b in range(0, len(src), bs)]
+    return np.concatenate(out, 0)
+
+
+def test_train_houv_driver_on_the_val_file(tmp_path):
     from houv_amd.drivers import train_houv
-    cfg = tmp_path / "houv.yaml"
-    cfg.write_text(f"batch_size: 4\nworkers: 0\nmodel_name: houv\nload_model: null\nwork_dir: {tmp_path}/log/\nflag: t\n"
-                   "manual_seed: 2021\nnum_points: 256\nbenchmark: mvp\nkernel: 32\nlr: 0.01\n")
-    res = train_houv.main(["-c", str(cfg), "--pairs", "8", "--kernel", "26", "--iters", "60"])
+    res = train_houv.main(["-c", _cfg(tmp_path, 4), "--kernel", "26", "--iters", "80"])
     assert set(res) == {"RotE", "transE", "MSE"} and np.isfinite(list(res.values())).all()
-    assert res["RotE"] < 60.0          # 8 easy-ish 256-pt pairs, 60 iterations: far better than chance (~90 deg)
+    assert res["RotE"] < 60.0          # 12 partial-overlap 128-pt pairs, 80 iterations: far better than chance (~90 deg)
+    # synthetic fallback when the file is absent (it is not shipped)
+    res = train_houv.main(["-c", _cfg(tmp_path, 4, data_dir=str(tmp_path / "nodata"), points=256), "--pairs", "8",
+                           "--kernel", "26", "--iters", "60"])
+    assert np.isfinite(list(res.values())).all() and res["RotE"] < 60.0
 
 
-def test_test_mult_driver_shards_and_combine(tmp_path):
+def test_test_mult_shards_combine_and_results_h5_equal_direct_solve(tmp_path):
+    from houv_amd import io as hio
     from houv_amd.drivers import test_mult
-    cfg = tmp_path / "houv.yaml"
-    cfg.write_text(f"batch_size: 2\nmodel_name: houv\nwork_dir: {tmp_path}/log/\nmanual_seed: 2021\nnum_points: 128\n")
-    np.random.seed(0)
-    a = test_mult.main(["-c", str(cfg), "-l", "0", "-r", "2", "--kernel", "26", "--iters", "15"])
-    b = test_mult.main(["-c", str(cfg), "-l", "2", "-r", "4", "--kernel", "26", "--iters", "15"])
-    assert a.shape == (2, 4, 4) and np.all(a[:, 3, :] == 0)
-    full = test_mult.main(["-c", str(cfg), "-l", "0", "-r", "2", "--combine", "True"])
-    np.testing.assert_array_equal(full, np.concatenate([a, b], 0))
-    assert os.path.exists(os.path.join(str(tmp_path), "log", "houv", "results.npy"))
+    E = np.load(os.path.join(MINI, "expected.npz"))
+    src, tgt = E["test__rotated_src"], E["test__rotated_tgt"]
+    cfg, K, iters, bs = _cfg(tmp_path, 4), 26, 15, 4
+    parts = [test_mult.main(["-c", cfg, "-l", str(l), "-r", str(l + 6), "--kernel", str(K), "--iters", str(iters)])
+             for l in (0, 6)]
+    for l, p in zip((0, 6), parts):
+        assert p.shape == (6, 4, 4) and np.all(p[:, 3, :] == 0)
+        np.testing.assert_array_equal(p, _direct_solve(src[l:l + 6], tgt[l:l + 6], bs, K, iters))     # bit for bit
+    full = test_mult.main(["-c", cfg, "--combine", "True", "--step", "6", "--num", "2"])
+    np.testing.assert_array_equal(full, np.concatenate(parts, 0))
+    log_dir = os.path.join(str(tmp_path), "log", "houv_mvp_t")
+    back = hio.load_results(os.path.join(log_dir, "results.h5"))                  # test.py:70-71's dataset, re-read
+    assert back.dtype == np.float32 and np.array_equal(back, full)
+    assert os.path.exists(os.path.join(log_dir, "submission.zip"))
+
+
+def test_test_driver_results_h5_equal_direct_solve(tmp_path):
+    from houv_amd import io as hio
+    from houv_amd.drivers import test as test_drv
+    E = np.load(os.path.join(MINI, "expected.npz"))
+    res, out = test_drv.main(["-c", _cfg(tmp_path, 5), "--kernel", "26", "--iters", "15"])
+    np.testing.assert_array_equal(res, _direct_solve(E["test__rotated_src"], E["test__rotated_tgt"], 5, 26, 15))
+    assert np.array_equal(hio.load_results(out), res) and res.shape == (12, 4, 4) and np.all(res[:, 3, :] == 0)

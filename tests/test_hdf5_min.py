@@ -50,8 +50,13 @@ def test_load_mvp_rg_reads_the_keys_the_reference_reads():
     path = os.path.join(GOLD, "g10_mvp_like.h5")
     d = hio.load_mvp_rg(path)
     for k in ("src", "tgt", "rotated_src", "rotated_tgt", "transforms", "pose_src", "cat_labels", "match_level",
-              "match_id", "rot_level"):
+              "rot_level"):
         assert np.array_equal(d[k], EXPECTED[k]), k
+    # this older fixture stores match_id as a plain [n,2] dataset (MVP's real files hold a GROUP of ragged lists --
+    # test_data_path.py covers that layout); it is only served on request and then per pair
+    assert "match_id" not in d
+    m = hio.load_mvp_rg(path, 1, 4, match_id=True)["match_id"]
+    assert len(m) == 3 and np.array_equal(np.stack(m), EXPECTED["match_id"][1:4])
     assert "complete" not in d and "pose_tgt" not in d                   # absent keys are skipped, not errors
     s = hio.load_mvp_rg(path, 2, 5)
     assert s["src"].shape == (3, 64, 3) and np.array_equal(s["cat_labels"], EXPECTED["cat_labels"][2:5])
