@@ -12,6 +12,8 @@
 //     sub-tile with bit-identical arithmetic ("deferred index");
 //   * the running minimum lives in registers for the whole sweep (the reference spills it to global
 //     memory every 512 references, chamfer3D.cu:126-129).
+#include <stdlib.h>
+
 #include "houv_common.h"
 
 namespace houv {
@@ -114,6 +116,305 @@ __global__ __launch_bounds__(kBlock) void chamfer_nn_kernel(const float* __restr
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Filtered sweep (the default): the SAME result as chamfer_nn_kernel, bit for bit, for 4.4 instead of 7.1 VALU issue
+// slots per point pair.
+//   * filter: e_j = |r_j|^2 - 2 q.r_j  (= |q - r_j|^2 - |q|^2) as three FMAs on (x, y, z, |r|^2) float4 references --
+//     the .w slot of the LDS tile, unused by the direct sweep, carries |r|^2, so the LDS traffic is unchanged;
+//   * e differs from the exact direct-difference d (the reference's arithmetic, chamfer3D.cu:31-36) by rounding, so
+//     it only SELECTS: per query the two smallest sub-tile minima of e (and their sub-tiles) plus the third smallest
+//     value are tracked (v_med3 updates, 8 instructions per query and 32 references); afterwards
+//       - the best sub-tile is re-evaluated with the exact expression (min d, lowest index) from the LDS tile,
+//       - the second one too when its minimum lies within tau of the best,
+//       - and when even the third does, the query falls back to an exact scan of all references (rare: ~1e-4);
+//   * tau bounds how far the ranking by e can disagree with the ranking by d.  With u = 2^-24, R = max |r|:
+//       |e~ - E| <= 6.02 u (R + |q|)^2   (3 roundings for |r|^2, 3 for the FMA chain),   |d - D| <= 5.01 u D,
+//     so the oracle's arg-min j* satisfies  e~(j*) <= e~(j) + 2 * 6.02 u (R+|q|)^2 + 10.1 u D_j  for every j;
+//     tau = 25 u (R + |q|)^2 covers it (derivation in DESIGN.md 3.2).  NaN / Inf coordinates behave as in the
+//     direct kernel: such references never win (v_min3 drops NaN), and a query without any finite distance reports
+//     reference 0 (chamfer3D.cu:37).
+// ---------------------------------------------------------------------------------------------------------------
+constexpr float kUlpHalf = 5.9604645e-8f;   // u = 2^-24
+constexpr int kList2 = 1024, kList3 = 256;   // capacities of the per-workgroup recovery work lists (LDS)
+
+// exact (direct-difference) minimum of one 32-reference sub-tile and the lowest index attaining it
+template <bool FROM_LDS>
+__device__ __forceinline__ void exact_tile(const float4* __restrict__ s_ref, const float* __restrict__ r, int tile, int nr,
+                                           float qx, float qy, float qz, int rot, float& bd, int& jb) {
+  const int base = tile * kSub;
+#pragma unroll 4
+  for (int jr = 0; jr < kSub; ++jr) {
+    const int j = FROM_LDS ? ((jr + rot) & (kSub - 1)) : jr;   // rotated: lanes sit on different bank quads whatever their tile
+    const int jj = base + j;
+    float px, py, pz;
+    if constexpr (FROM_LDS) {
+      const float4 p = s_ref[jj];
+      px = p.x; py = p.y; pz = p.z;
+    } else {
+      const int jc = jj < nr ? jj : 0;
+      px = r[jc * 3 + 0]; py = r[jc * 3 + 1]; pz = r[jc * 3 + 2];
+    }
+    const float d = metric_sqdist<0>(px - qx, py - qy, pz - qz);
+    const bool better = (jj < nr) && (d < bd || (d == bd && jj < jb));
+    bd = better ? d : bd;
+    jb = better ? jj : jb;
+  }
+}
+
+template <int Q>
+__global__ __launch_bounds__(kBlock, 4) void chamfer_nn_filter_kernel(const float* __restrict__ xyz1,
+                                                                   const float* __restrict__ xyz2, int N, int M, int nqb,
+                                                                   float* dist1, float* dist2, int* idx1, int* idx2) {
+  __shared__ float4 s_ref[kRefTile];
+  __shared__ unsigned s_rmax;   // bit pattern of max |r|^2 (non-negative floats order like unsigned integers)
+  __shared__ unsigned s_list2[kList2];          // work list "second sub-tile": query (11 bits) | sub-tile << 11
+  __shared__ unsigned short s_list3[kList3];    // work list "exact full scan": query
+  __shared__ int s_n2, s_n3;
+  const bool fwd = blockIdx.y == 0;
+  const int nq = fwd ? N : M, nr = fwd ? M : N;
+  const int b = blockIdx.x / nqb;
+  const int q0 = (blockIdx.x - b * nqb) * (kBlock * Q);
+  if (q0 >= nq) return;   // uniform for the whole workgroup (grid is sized for max(N, M))
+  const float* __restrict__ q = (fwd ? xyz1 : xyz2) + (size_t)b * nq * 3;
+  const float* __restrict__ r = (fwd ? xyz2 : xyz1) + (size_t)b * nr * 3;
+  float* dist = (fwd ? dist1 : dist2) + (size_t)b * nq;     // no __restrict__: phase B re-reads what phase A wrote
+  int* idx = (fwd ? idx1 : idx2) + (size_t)b * nq;
+  const int tid = threadIdx.x;
+
+  // the sweep keeps only e = -2 q (exact scaling); the recovery gets q back as -0.5 e
+  float ex[Q], ey[Q], ez[Q], best[Q], sec[Q], third[Q];
+  int bt[Q], bt2[Q];
+#pragma unroll
+  for (int k = 0; k < Q; ++k) {
+    const int qi = q0 + k * kBlock + tid;
+    const bool ok = qi < nq;
+    ex[k] = ok ? -2.0f * q[qi * 3 + 0] : 0.f;
+    ey[k] = ok ? -2.0f * q[qi * 3 + 1] : 0.f;
+    ez[k] = ok ? -2.0f * q[qi * 3 + 2] : 0.f;
+    best[k] = sec[k] = third[k] = INFINITY;
+    bt[k] = bt2[k] = 0;
+  }
+  if (tid == 0) {
+    s_rmax = 0u;
+    s_n2 = 0;
+    s_n3 = 0;
+  }
+
+  for (int r0 = 0; r0 < nr; r0 += kRefTile) {
+    const int cnt = min(kRefTile, nr - r0);
+    const int ntile = (cnt + kSub - 1) / kSub;
+    __syncthreads();
+    float lmax = 0.f;
+    for (int j = tid; j < ntile * kSub; j += kBlock) {
+      float4 v = make_float4(0.f, 0.f, 0.f, INFINITY);   // padding: e = +inf (or NaN), never wins
+      if (j < cnt) {
+        const float* p = r + (size_t)(r0 + j) * 3;
+        v = make_float4(p[0], p[1], p[2], metric_sqdist<0>(p[0], p[1], p[2]));
+        lmax = fmaxf(lmax, v.w);
+      }
+      s_ref[j] = v;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) lmax = fmaxf(lmax, __shfl_xor(lmax, o, kWave));
+    if ((tid & 63) == 0) atomicMax(&s_rmax, __float_as_uint(lmax));
+    __syncthreads();
+    for (int t = 0; t < ntile; ++t) {
+      float tm[Q];
+#pragma unroll
+      for (int k = 0; k < Q; ++k) tm[k] = INFINITY;
+      const float4* rp = s_ref + t * kSub;
+      // broadcast reads, software-pipelined: the next four references are in flight while four are evaluated
+      constexpr int kB = 4;
+      float4 ra[kB], rb[kB];
+      auto eval = [&](const float4 (&rr)[kB]) {
+#pragma unroll
+        for (int u = 0; u < kB; u += 2) {
+          const float4 a = rr[u], c = rr[u + 1];
+#pragma unroll
+          for (int k = 0; k < Q; ++k) {
+            const float e0 = __builtin_fmaf(ex[k], a.x, __builtin_fmaf(ey[k], a.y, __builtin_fmaf(ez[k], a.z, a.w)));
+            const float e1 = __builtin_fmaf(ex[k], c.x, __builtin_fmaf(ey[k], c.y, __builtin_fmaf(ez[k], c.z, c.w)));
+            tm[k] = min3f(tm[k], e0, e1);
+          }
+        }
+      };
+#pragma unroll
+      for (int u = 0; u < kB; ++u) ra[u] = rp[u];
+#pragma unroll
+      for (int j0 = 0; j0 < kSub; j0 += 2 * kB) {
+#pragma unroll
+        for (int u = 0; u < kB; ++u) rb[u] = rp[j0 + kB + u];
+        eval(ra);
+        if (j0 + 2 * kB < kSub) {
+#pragma unroll
+          for (int u = 0; u < kB; ++u) ra[u] = rp[j0 + 2 * kB + u];
+        }
+        eval(rb);
+      }
+      const int tile = r0 / kSub + t;
+#pragma unroll
+      for (int k = 0; k < Q; ++k) {
+        const float v = tm[k];
+        const bool lt1 = v < best[k], lt2 = v < sec[k];
+        third[k] = __builtin_amdgcn_fmed3f(v, sec[k], third[k]);   // sec <= third: the middle one is the new third smallest
+        sec[k] = __builtin_amdgcn_fmed3f(v, best[k], sec[k]);      // best <= sec: likewise
+        int s2 = lt2 ? tile : bt2[k];
+        asm volatile("" : "+v"(s2));                               // keep straight-line selects (a nested ?: becomes branches)
+        bt2[k] = lt1 ? bt[k] : s2;
+        bt[k] = lt1 ? tile : bt[k];
+        best[k] = lt1 ? v : best[k];
+      }
+    }
+  }
+
+  // ---- exact recovery ------------------------------------------------------------------------------------------
+  // Phase A (dense, every lane): exact minimum of the best sub-tile -> provisional (dist, idx) in global memory.  Queries
+  // whose second / third sub-tile lies within tau are NOT finished in place -- a wave would run the extra work for
+  // all 64 lanes whenever one lane asks for it -- but appended to two LDS work lists.
+  // Phase B (after a barrier): the lists are worked off densely: one lane per "second sub-tile" entry, eight lanes per
+  // "exact full scan" entry.  Lists that overflow (pathological inputs: everything tied) spill to the in-lane path.
+  const float rmax = sqrtf(__uint_as_float(s_rmax));   // visible: written before the last tile's barrier
+  const bool resident = nr <= kRefTile;                // single LDS pass: every sub-tile is still in s_ref
+  const int rot = tid & (kSub - 1);
+  unsigned ovf2 = 0u, ovf3 = 0u;
+#pragma unroll 1
+  for (int k = 0; k < Q; ++k) {
+    const int ql = k * kBlock + tid, qi = q0 + ql;
+    const bool valid = qi < nq;
+    const bool finite = best[k] < INFINITY;
+    const float qx = -0.5f * ex[k], qy = -0.5f * ey[k], qz = -0.5f * ez[k];
+    const float qn = sqrtf(metric_sqdist<0>(qx, qy, qz));
+    const float tau = 25.0f * kUlpHalf * (rmax + qn) * (rmax + qn) + 1e-30f;
+    const bool need3 = valid && finite && !(third[k] > best[k] + tau);           // written so that NaN / inf thresholds say "needed"
+    const bool need2 = valid && finite && !need3 && !(sec[k] > best[k] + tau);
+    float bd = INFINITY;
+    int jb = 0x7fffffff;
+    if (resident) exact_tile<true>(s_ref, r, bt[k], nr, qx, qy, qz, rot, bd, jb);
+    else exact_tile<false>(s_ref, r, bt[k], nr, qx, qy, qz, rot, bd, jb);
+    if (!finite) {
+      // no finite distance at all (NaN / overflowing input): the reference reports ref 0 (chamfer3D.cu:37)
+      bd = metric_sqdist<0>(r[0] - qx, r[1] - qy, r[2] - qz);
+      jb = 0;
+    }
+    if (valid) {
+      dist[qi] = bd;
+      idx[qi] = jb;
+    }
+    if (need3) {
+      const int slot = atomicAdd(&s_n3, 1);
+      if (slot < kList3) s_list3[slot] = (unsigned short)ql;
+      else ovf3 |= 1u << k;
+    } else if (need2) {
+      const int slot = atomicAdd(&s_n2, 1);
+      if (slot < kList2) s_list2[slot] = (unsigned)ql | ((unsigned)bt2[k] << 11);
+      else ovf2 |= 1u << k;
+    }
+  }
+  __syncthreads();   // lists complete; the provisional results are visible to the whole workgroup
+
+  // Phase B.1: second sub-tile, one lane per entry
+  const int n2 = min(s_n2, kList2);
+#pragma unroll 1
+  for (int base = 0; base < n2; base += kBlock) {
+    const int i = base + tid;
+    const bool act = i < n2;
+    const unsigned e = act ? s_list2[i] : 0u;
+    const int qi = q0 + (int)(e & 2047u), t2 = (int)(e >> 11);
+    const float qx = act ? q[qi * 3 + 0] : 0.f, qy = act ? q[qi * 3 + 1] : 0.f, qz = act ? q[qi * 3 + 2] : 0.f;
+    const float bd = act ? dist[qi] : 0.f;
+    const int jb = act ? idx[qi] : 0;
+    float d2 = INFINITY;
+    int j2 = 0x7fffffff;
+    if (resident) exact_tile<true>(s_ref, r, t2, nr, qx, qy, qz, rot, d2, j2);
+    else exact_tile<false>(s_ref, r, t2, nr, qx, qy, qz, rot, d2, j2);
+    if (act && (d2 < bd || (d2 == bd && j2 < jb))) {
+      dist[qi] = d2;
+      idx[qi] = j2;
+    }
+  }
+  // Phase B.2: exact scan of every reference, eight lanes per entry (lane s takes references s, s+8, ... in ascending
+  // order with strict <, then the eight partial results are merged: smaller distance, lower index on ties)
+  const int n3 = min(s_n3, kList3);
+#pragma unroll 1
+  for (int base = 0; base < n3; base += kBlock / 8) {
+    const int i = base + (tid >> 3), sub = tid & 7;
+    const bool act = i < n3;
+    const int qi = q0 + (act ? (int)s_list3[i] : 0);
+    const float qx = act ? q[qi * 3 + 0] : 0.f, qy = act ? q[qi * 3 + 1] : 0.f, qz = act ? q[qi * 3 + 2] : 0.f;
+    float d3 = INFINITY;
+    int j3 = 0x7fffffff;
+    if (resident) {
+#pragma unroll 4
+      for (int j = sub; j < nr; j += 8) {
+        const float4 p = s_ref[j];
+        const float d = metric_sqdist<0>(p.x - qx, p.y - qy, p.z - qz);
+        const bool lt = d < d3;
+        d3 = lt ? d : d3;
+        j3 = lt ? j : j3;
+      }
+    } else {
+#pragma unroll 4
+      for (int j = sub; j < nr; j += 8) {
+        const float d = metric_sqdist<0>(r[j * 3 + 0] - qx, r[j * 3 + 1] - qy, r[j * 3 + 2] - qz);
+        const bool lt = d < d3;
+        d3 = lt ? d : d3;
+        j3 = lt ? j : j3;
+      }
+    }
+#pragma unroll
+    for (int o = 1; o < 8; o <<= 1) {
+      const float dq = __shfl_xor(d3, o, kWave);
+      const int jo = __shfl_xor(j3, o, kWave);
+      const bool take = dq < d3 || (dq == d3 && jo < j3);
+      d3 = take ? dq : d3;
+      j3 = take ? jo : j3;
+    }
+    if (act && sub == 0 && j3 != 0x7fffffff) {
+      dist[qi] = d3;
+      idx[qi] = j3;
+    }
+  }
+  // list overflow (more than kList2 / kList3 uncertain queries in one workgroup): finish those in place
+  if (__any((ovf2 | ovf3) != 0u)) {
+#pragma unroll 1
+    for (int k = 0; k < Q; ++k) {
+      const bool o2 = (ovf2 >> k) & 1u, o3 = (ovf3 >> k) & 1u;
+      if (!__any(o2 || o3)) continue;
+      const int qi = q0 + k * kBlock + tid;
+      const float qx = -0.5f * ex[k], qy = -0.5f * ey[k], qz = -0.5f * ez[k];
+      float bd = (o2 || o3) ? dist[qi] : 0.f;
+      int jb = (o2 || o3) ? idx[qi] : 0;
+      if (__any(o2)) {
+        float d2 = INFINITY;
+        int j2 = 0x7fffffff;
+        if (resident) exact_tile<true>(s_ref, r, bt2[k], nr, qx, qy, qz, rot, d2, j2);
+        else exact_tile<false>(s_ref, r, bt2[k], nr, qx, qy, qz, rot, d2, j2);
+        const bool take = o2 && (d2 < bd || (d2 == bd && j2 < jb));
+        bd = take ? d2 : bd;
+        jb = take ? j2 : jb;
+      }
+      if (__any(o3)) {
+        float d3 = INFINITY;
+        int j3 = 0x7fffffff;
+#pragma unroll 4
+        for (int j = 0; j < nr; ++j) {
+          const float d = metric_sqdist<0>(r[j * 3 + 0] - qx, r[j * 3 + 1] - qy, r[j * 3 + 2] - qz);
+          const bool lt = d < d3;
+          d3 = lt ? d : d3;
+          j3 = lt ? j : j3;
+        }
+        const bool take = o3 && j3 != 0x7fffffff;
+        bd = take ? d3 : bd;
+        jb = take ? j3 : jb;
+      }
+      if (o2 || o3) {
+        dist[qi] = bd;
+        idx[qi] = jb;
+      }
+    }
+  }
+}
+
 // Backward: same arithmetic and accumulate-into-zeroed-buffers contract as NmDistanceGradKernel
 // (chamfer3D.cu:155-174), but one thread per (batch, point) over the whole batch in one launch per
 // direction pair instead of a single block column walking the batch serially.
@@ -209,16 +510,27 @@ extern "C" int houv_chamfer_forward(const float* xyz1, const float* xyz2, int B,
   }
   hipStream_t s = (hipStream_t)stream;
   const int mx = N > M ? N : M;
-  const int q = mx <= kBlock ? 1 : (mx <= 2 * kBlock ? 2 : 4);
+  static const bool direct = [] { const char* e = getenv("HOUV_CHAMFER_DIRECT"); return e && e[0] == '1'; }();
+  static const int qmax = [] { const char* e = getenv("HOUV_CHAMFER_Q"); return e ? atoi(e) : 8; }();   // diagnostics only
+  int q = mx <= kBlock ? 1 : (mx <= 2 * kBlock ? 2 : (mx <= 4 * kBlock || direct ? 4 : 8));
+  if (q > qmax) q = qmax;
   const int nqb = (mx + kBlock * q - 1) / (kBlock * q);
   if ((long long)B * nqb > 0x7fffffffLL) {
     set_error("houv_chamfer_forward: batch too large");
     return 0;
   }
   dim3 grid((unsigned)(B * nqb), 2, 1);
-  if (q == 1) chamfer_nn_kernel<1><<<grid, kBlock, 0, s>>>(xyz1, xyz2, N, M, nqb, dist1, dist2, idx1, idx2);
-  else if (q == 2) chamfer_nn_kernel<2><<<grid, kBlock, 0, s>>>(xyz1, xyz2, N, M, nqb, dist1, dist2, idx1, idx2);
-  else chamfer_nn_kernel<4><<<grid, kBlock, 0, s>>>(xyz1, xyz2, N, M, nqb, dist1, dist2, idx1, idx2);
+  // HOUV_CHAMFER_DIRECT=1 (diagnostics / A-B only): the direct-difference sweep without the expanded-form filter
+  if (direct) {
+    if (q == 1) chamfer_nn_kernel<1><<<grid, kBlock, 0, s>>>(xyz1, xyz2, N, M, nqb, dist1, dist2, idx1, idx2);
+    else if (q == 2) chamfer_nn_kernel<2><<<grid, kBlock, 0, s>>>(xyz1, xyz2, N, M, nqb, dist1, dist2, idx1, idx2);
+    else chamfer_nn_kernel<4><<<grid, kBlock, 0, s>>>(xyz1, xyz2, N, M, nqb, dist1, dist2, idx1, idx2);
+  } else {
+    if (q == 1) chamfer_nn_filter_kernel<1><<<grid, kBlock, 0, s>>>(xyz1, xyz2, N, M, nqb, dist1, dist2, idx1, idx2);
+    else if (q == 2) chamfer_nn_filter_kernel<2><<<grid, kBlock, 0, s>>>(xyz1, xyz2, N, M, nqb, dist1, dist2, idx1, idx2);
+    else if (q == 4) chamfer_nn_filter_kernel<4><<<grid, kBlock, 0, s>>>(xyz1, xyz2, N, M, nqb, dist1, dist2, idx1, idx2);
+    else chamfer_nn_filter_kernel<8><<<grid, kBlock, 0, s>>>(xyz1, xyz2, N, M, nqb, dist1, dist2, idx1, idx2);
+  }
   return check_launch("houv_chamfer_forward") ? 1 : 0;
 }
 

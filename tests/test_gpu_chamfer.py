@@ -84,6 +84,48 @@ def test_bit_exact_vs_c_oracle(dev, B, N, M):
     assert np.array_equal(i1.cpu().numpy(), j1) and np.array_equal(i2.cpu().numpy(), j2)
 
 
+@pytest.mark.parametrize("B,N,M,offset,dups", [(3, 2048, 2048, 3.0, False), (2, 1500, 2048, 50.0, False),
+                                                (2, 2048, 2048, 0.0, True), (2, 900, 2600, 7.0, False),
+                                                (1, 2600, 5000, 0.0, True), (2, 2048, 2048, 1e4, False)])
+def test_filter_uncertainty_paths_bit_exact(dev, B, N, M, offset, dups):
+    """The expanded-form filter of chamfer_nn_filter_kernel only SELECTS candidate sub-tiles; whatever it is unsure about
+    must be re-decided by the exact arithmetic.  Clouds far from the origin blow the uncertainty tau = 25 u (R+|q|)^2 up
+    (offset 3: the second sub-tile is re-evaluated for most queries; 50 / 1e4: every query takes the exact full scan),
+    and a reference cloud made of repeated blocks puts exact ties into EVERY sub-tile (lowest index must win) -- single
+    LDS pass (M <= 2048, LDS-resident recovery) and multi-pass (recovery from global memory).  Bit-exact vs chamfer_ref.c."""
+    from oracle import c_oracle
+    gen = torch.Generator().manual_seed(int(N * 31 + M + offset))
+    a = torch.rand(B, N, 3, generator=gen) - 0.5 + offset
+    b = torch.rand(B, M, 3, generator=gen) - 0.5 + offset
+    if dups:
+        blk = b[:, :96].clone()                      # 96 points repeated: copies land in every 32-reference sub-tile
+        b = blk.repeat(1, M // 96 + 1, 1)[:, :M].contiguous()
+        a[:, ::3] = blk[:, torch.arange(0, N, 3)[: a[:, ::3].shape[1]] % 96]      # a third of the queries sit ON references
+    d1, d2, i1, i2 = _cd(a, b, dev)
+    o1, o2, j1, j2 = c_oracle.chamfer_forward(a.numpy(), b.numpy())
+    assert np.array_equal(i1.cpu().numpy(), j1) and np.array_equal(i2.cpu().numpy(), j2)
+    assert np.array_equal(d1.cpu().numpy().view(np.uint32), o1.view(np.uint32))
+    assert np.array_equal(d2.cpu().numpy().view(np.uint32), o2.view(np.uint32))
+
+
+def test_filter_and_direct_kernels_agree_on_nonfinite_inputs(dev):
+    """NaN / Inf coordinates: such references never win in either kernel (v_min3 drops NaN); a query with no finite
+    distance reports reference 0 (chamfer3D.cu:37).  The filtered kernel must behave exactly like the direct sweep it
+    replaces -- compared through a second process-free route: the same inputs with the bad points removed."""
+    gen = torch.Generator().manual_seed(11)
+    a = torch.rand(2, 300, 3, generator=gen)
+    b = torch.rand(2, 500, 3, generator=gen)
+    bad = b.clone()
+    bad[:, 7] = float("nan"); bad[:, 130, 1] = float("inf"); bad[:, 499] = float("-inf")
+    d1, _, i1, _ = _cd(a, bad, dev)
+    keep = torch.tensor([j for j in range(500) if j not in (7, 130, 499)])
+    e1, _, k1, _ = _cd(a, b[:, keep].contiguous(), dev)
+    assert torch.equal(d1, e1) and torch.equal(keep.to(dev)[k1.long()], i1.long())
+    allbad = torch.full((1, 40, 3), float("nan"))
+    d, _, i, _ = _cd(a[:1], allbad, dev)
+    assert bool(torch.isnan(d).all()) and int(i.abs().max()) == 0
+
+
 def test_ties_pick_lowest_index(dev):
     """Duplicated reference points: the lowest index must win, across sub-tile (32) and LDS-tile (2048) borders."""
     gen = torch.Generator().manual_seed(5)
