@@ -189,6 +189,8 @@ def register_torch_ops():
 def knn(xyz, k):
     """xyz[B,N,3] -> idx[B,N,k] int32, nearest first, self included (dcp.py:35-42)."""
     _lib.require_gpu(xyz); _want(xyz, _F32, "xyz")
+    if xyz.dim() != 3 or xyz.shape[2] != 3:
+        raise _lib.HouvHipError("knn: expected xyz[B,N,3]")
     B, N, _ = xyz.shape
     idx = torch.empty((B, N, k), dtype=_I32, device=xyz.device)
     with torch.cuda.device(xyz.device):
@@ -200,6 +202,12 @@ def knn(xyz, k):
 def edgeconv1(xyz, idx, W, scale, shift):
     """-> act[B*N*k, 64] = relu(scale * conv1(cat(neighbour, centre)) + shift)."""
     _lib.require_gpu(xyz, idx, W, scale, shift)
+    for t, d, n in ((xyz, _F32, "xyz"), (idx, _I32, "idx"), (W, _F32, "W"), (scale, _F32, "scale"), (shift, _F32, "shift")):
+        _want(t, d, n)
+    if idx.dim() != 3 or xyz.dim() != 3 or xyz.shape[2] != 3 or idx.shape[:2] != xyz.shape[:2]:
+        raise _lib.HouvHipError("edgeconv1: expected xyz[B,N,3], idx[B,N,k]")
+    if tuple(W.shape) != (64, 6) or scale.numel() != 64 or shift.numel() != 64:
+        raise _lib.HouvHipError("edgeconv1: expected W[64,6], scale[64], shift[64]")
     B, N, k = idx.shape
     out = torch.empty((B * N * k, 64), dtype=_F32, device=xyz.device)
     with torch.cuda.device(xyz.device):
@@ -211,8 +219,12 @@ def edgeconv1(xyz, idx, W, scale, shift):
 
 def max_over_k(act, k, out, col0):
     """out[:, col0:col0+C] = max over groups of k consecutive rows of act[npts*k, C]."""
-    _lib.require_gpu(act, out)
+    _lib.require_gpu(act); _lib.require_gpu_any(out)
+    _want(act, _F32, "act"); _want(out, _F32, "out")
     C = act.shape[1]
+    if act.dim() != 2 or act.shape[0] % k or C % 4 or out.stride(0) % 4 or out.stride(1) != 1 \
+            or out.shape[0] != act.shape[0] // k or col0 + C > out.shape[1]:
+        raise _lib.HouvHipError("max_over_k: expected act[npts*k,C], out[npts, >= col0+C] (C and the row stride multiples of 4)")
     npts = act.shape[0] // k
     view = out[:, col0:col0 + C]
     with torch.cuda.device(act.device):
@@ -272,7 +284,12 @@ def gemm(A, B, C=None, *, trans_b=True, alpha=1.0, scale=None, shift=None, resid
 
 def layernorm(x, a, b, eps=1e-6, residual=None):
     _lib.require_gpu(x, a, b, residual)
+    for t, n in ((x, "x"), (a, "a"), (b, "b"), (residual, "residual")):
+        if t is not None:
+            _want(t, _F32, n)
     D = x.shape[-1]
+    if a.numel() != D or b.numel() != D or (residual is not None and residual.shape != x.shape):
+        raise _lib.HouvHipError("layernorm: a, b must have D elements and residual the shape of x")
     rows = x.numel() // D
     out = torch.empty_like(x)
     with torch.cuda.device(x.device):
@@ -283,7 +300,7 @@ def layernorm(x, a, b, eps=1e-6, residual=None):
 
 
 def softmax_rows_(x):
-    _lib.require_gpu(x)
+    _lib.require_gpu(x); _want(x, _F32, "x")
     L = x.shape[-1]
     with torch.cuda.device(x.device):
         ok = _lib.load().houv_softmax_rows(_lib.ptr(x), x.numel() // L, L, _lib.stream_of(x))
@@ -293,7 +310,9 @@ def softmax_rows_(x):
 
 def softmax_corr(scores, pts):
     """scores[P,N,M], pts[P,M,3] -> corr[P,3,N] = pts^T softmax(scores)^T."""
-    _lib.require_gpu(scores, pts)
+    _lib.require_gpu(scores, pts); _want(scores, _F32, "scores"); _want(pts, _F32, "pts")
+    if scores.dim() != 3 or tuple(pts.shape) != (scores.shape[0], scores.shape[2], 3):
+        raise _lib.HouvHipError("softmax_corr: expected scores[P,N,M], pts[P,M,3]")
     P, N, M = scores.shape
     corr = torch.empty((P, 3, N), dtype=_F32, device=scores.device)
     with torch.cuda.device(scores.device):

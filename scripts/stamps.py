@@ -30,5 +30,5 @@ for views in (True, False):
     print(f"views={views}: {e0.elapsed_time(e1):.1f} ms, {e0.elapsed_time(e1)*1e3/(P*K*iters):.3f} us/hyp-iter")
     for n, x, y in zip(names[:7], v[:7], per[:7]):
         print(f"   {n:10s} {100*x/tot:5.1f} %   {y/1e3:8.1f} kcycles per wave-iteration")
-    for n, i in (("  epi:rescan", 8), ("  epi:select", 9), ("  epi:accumulate", 10), ("  epi:block_sum", 11)):
+    for n, i in (("  epi:select", 9), ("  epi:rescan+sums+wave-reduce", 8), ("  epi:barrier+final-sum", 11)):
         print(f"   {n:16s} {per[i]/1e3:8.1f} kcycles per wave-iteration (all metrics, both directions)")

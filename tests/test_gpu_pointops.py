@@ -64,3 +64,34 @@ def test_combine(dev):
     from houv_amd.mm3d_pn2 import furthest_point_sample
     idx = furthest_point_sample(allp.contiguous(), 2048).long()
     assert torch.equal(c, torch.gather(allp, 1, idx.unsqueeze(2).expand(-1, -1, 3)))
+
+
+def test_wrappers_validate_dtypes_and_indices(dev):
+    """ADVICE r1: torch-default int64 indices (argsort / topk) and non-fp32 features must not be reinterpreted silently;
+    out-of-range indices must be refused (the gather kernel does not bounds-check)."""
+    from houv_amd import _lib, ops
+    from houv_amd.mm3d_pn2 import furthest_point_sample, gather_points, three_nn
+    g = torch.Generator().manual_seed(0)
+    feats = torch.rand(2, 5, 40, generator=g).to(dev)
+    idx64 = torch.argsort(torch.rand(2, 40, generator=g), dim=1)[:, :7].to(dev)          # int64, like torch.topk / argsort give
+    want = torch.gather(feats, 2, idx64.unsqueeze(1).expand(2, 5, 7))
+    assert torch.equal(gather_points(feats, idx64), want)
+    assert torch.equal(gather_points(feats.double(), idx64.int()), want)                 # fp64 features are converted, not reinterpreted
+    with pytest.raises(_lib.HouvHipError):
+        gather_points(feats, torch.full((2, 3), 40, dtype=torch.int64, device=dev))      # out of range
+    with pytest.raises(_lib.HouvHipError):
+        gather_points(feats, idx64.float())
+    pts = torch.rand(2, 64, 3, generator=g).to(dev)
+    assert torch.equal(furthest_point_sample(pts.double(), 9), furthest_point_sample(pts, 9))
+    with pytest.raises(_lib.HouvHipError):
+        furthest_point_sample(pts, 65)
+    d_a, i_a = three_nn(pts.double(), pts[:, :20].double())
+    d_b, i_b = three_nn(pts, pts[:, :20].contiguous())
+    assert torch.equal(i_a, i_b) and torch.equal(d_a, d_b)
+    with pytest.raises(_lib.HouvHipError):
+        ops.softmax_rows_(torch.rand(4, 8, device=dev).double())
+    with pytest.raises(_lib.HouvHipError):
+        ops.layernorm(torch.rand(4, 8, device=dev), torch.ones(7, device=dev), torch.zeros(8, device=dev))
+    with pytest.raises(_lib.HouvHipError):
+        ops.edgeconv1(pts, torch.zeros(2, 64, 20, dtype=torch.int64, device=dev), torch.rand(64, 6, device=dev),
+                      torch.ones(64, device=dev), torch.zeros(64, device=dev))
