@@ -67,6 +67,40 @@ __device__ __forceinline__ void sweep(const float4* __restrict__ refs, int ntile
   }
 }
 
+// Single-metric form of sweep() for metric MET (used by the fused loop's mis-prediction repair): the same expression
+// tree per metric (metric_sqdist<MET> == the a0..a3 of the fused form), the same min3 / strict-< bookkeeping, hence
+// bit-identical (best, btile) for that metric.
+template <int Q, int MET>
+__device__ __forceinline__ void sweep_one(const float4* __restrict__ refs, int ntile, const float (&qx)[Q],
+                                          const float (&qy)[Q], const float (&qz)[Q], float (&best)[Q], int (&btile)[Q]) {
+#pragma unroll
+  for (int k = 0; k < Q; ++k) {
+    best[k] = INFINITY;
+    btile[k] = 0;
+  }
+  for (int t = 0; t < ntile; ++t) {
+    float tm[Q];
+#pragma unroll
+    for (int k = 0; k < Q; ++k) tm[k] = INFINITY;
+    const float4* rp = refs + t * kSub;
+#pragma unroll 4
+    for (int j = 0; j < kSub; j += 2) {
+      const float4 a = rp[j], c = rp[j + 1];
+      asm volatile("" ::"v"(a.w), "v"(c.w));
+#pragma unroll
+      for (int k = 0; k < Q; ++k)
+        tm[k] = min3f(tm[k], metric_sqdist<MET>(a.x - qx[k], a.y - qy[k], a.z - qz[k]),
+                      metric_sqdist<MET>(c.x - qx[k], c.y - qy[k], c.z - qz[k]));
+    }
+#pragma unroll
+    for (int k = 0; k < Q; ++k) {
+      const bool lt = tm[k] < best[k];
+      best[k] = lt ? tm[k] : best[k];
+      btile[k] = lt ? t : btile[k];
+    }
+  }
+}
+
 // Sum NV per-thread values over the workgroup into out[0..NV) (LDS).
 template <int BLOCK, int NV>
 __device__ __forceinline__ void block_sum(float (&v)[NV], float* red, float* out) {

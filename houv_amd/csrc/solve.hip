@@ -20,6 +20,8 @@
 //   * top-k (k = N/2 for the full metric) = exact 4-pass 8-bit radix select on the fp32 bit patterns
 //     of the register-resident distances, LDS histogram;
 //   * the un-moved source point needed for sum G p^T in the target->moved direction is R^T(p' - T).
+#include <stdlib.h>
+
 #include "../../include/houv_hip.h"
 #include "houv_common.h"
 #include "houv_sweep.h"
@@ -44,6 +46,8 @@ struct SolveArgs {
   short* nn_ws;      // pruned mode: [P*K][2 dirs][4 metrics][ws_stride] index of each query's NN in the last iteration
   int ws_valid;      //   1: nn_ws holds the NNs of the iteration before this launch's first one
   int ws_stride;
+  int pred_mode;     // diagnostics (HOUV_SOLVE_PREDICT): 0 normal; 1 always predict direction B (every A-win takes the
+                     // repair path); 2 rescan everything (no skipping: the round-1 epilogue's work)
 };
 
 #ifdef HOUV_STAMPS
@@ -198,22 +202,64 @@ __device__ __forceinline__ void select_smallest(const unsigned (&key)[Q], int ks
   }
 }
 
-// One metric of a sweep's epilogue: exact NN recovery + the 13 sums, per query (nothing is kept per query), then a
-// wave-level DPP reduction whose totals lane 63 parks in red[wave][MET*13 ..].  No barrier in here.
-//   DIR == 1: queries are this lane's moved points (count = N), references the target cloud.
-//   DIR == 0: queries are this lane's target points (count = M), references the moved cloud.
-//   S = sum sqrt(d),  G = sum c,  GP = sum c p^T,   c = mask * (moved - target) / sqrt(d),  p = un-moved source point
-template <int BLOCK, int Q, int NMET, int MET, int DIR, int OWN>
-__device__ __forceinline__ void epilogue_metric(const Smem& sm, const float4* __restrict__ refs, const float (&qx)[Q],
-                                                const float (&qy)[Q], const float (&qz)[Q], const float (&best)[Q][NMET],
-                                                const int (&btile)[Q][NMET], const bool (&sel)[Q], int count,
-                                                const float (&px)[Q], const float (&py)[Q], const float (&pz)[Q],
-                                                float* red_wave, short* ws) {
-  const int tid = threadIdx.x;
-  const int rot = tid & (kSub - 1);
-  float acc[kAccN];
+// ---- epilogue building blocks ------------------------------------------------------------------------------------
+// Per metric and direction the scalar tail needs   S = sum sqrt(d)   over the selected queries, and -- for the ONE
+// direction that wins the min of houv.py:212-221 -- G = sum c, GP = sum c p^T with c = mask * (moved - target) / sqrt(d),
+// p = un-moved source point.  S needs only the distances the sweep already holds; G and GP need the identity of the
+// nearest neighbour, i.e. the exact rescan of the winning sub-tile (32 references x ~11 instructions per query and
+// metric: 3/4 of the epilogue's instruction count).  Since round 2 the rescans run only where the gradient flows.
+//   DIR == 1 ("A"): queries are this lane's moved points (count = N), references the target cloud.
+//   DIR == 0 ("B"): queries are this lane's target points (count = M), references the moved cloud.
+constexpr int kGradN = 12;
+
+// wave-level DPP sum; lane 63 parks the total
+__device__ __forceinline__ void park(float v, float* dst) {
+  v = wave_sum_to_lane63(v);
+  if ((threadIdx.x & 63) == 63) *dst = v;
+}
+
+// selections of one direction: bit k of bits[m] = query k of this lane takes part in metric m's mean
+template <int BLOCK, int Q, int NMET, int OWN>
+__device__ __forceinline__ void select_all(const Smem& sm, const float (&best)[Q][NMET], int count, int k_full, int k_view,
+                                           int& hrot, unsigned (&bits)[NMET]) {
+  bool valid[Q], sel[Q];
+  unsigned key[Q];
 #pragma unroll
-  for (int i = 0; i < kAccN; ++i) acc[i] = 0.f;
+  for (int m = 0; m < NMET; ++m) {
+    const int ksel = (m == 0) ? k_full : k_view;     // the view terms take all points in every caller (k_view == count)
+#pragma unroll
+    for (int k = 0; k < Q; ++k) {
+      valid[k] = pt_index<BLOCK, Q, OWN>(k) < count;
+      key[k] = valid[k] ? __float_as_uint(best[k][m]) : 0xFFFFFFFFu;
+      sel[k] = valid[k];
+    }
+    if (ksel < count) select_smallest<BLOCK, Q>(key, ksel, sm.hist, sm.ctl, sel, hrot);
+    unsigned b = 0u;
+#pragma unroll
+    for (int k = 0; k < Q; ++k) b |= sel[k] ? (1u << k) : 0u;
+    bits[m] = b;
+  }
+}
+
+// this lane's share of S for one metric (k order; no finite distance -> NaN like torch's min/topk/sqrt chain)
+template <int Q>
+__device__ __forceinline__ float lane_sqrt_sum(const float (&bd)[Q], unsigned selbits) {
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < Q; ++k)
+    if ((selbits >> k) & 1u) s += (bd[k] < INFINITY) ? sqrtf(bd[k]) : NAN;
+  return s;
+}
+
+// this lane's share of G[3], GP[9] for one metric: exact NN recovery + products, per query (nothing is kept per query)
+template <int BLOCK, int Q, int MET, int DIR, int OWN>
+__device__ __forceinline__ void lane_grad_sums(const Smem& sm, const float4* __restrict__ refs, const float (&qx)[Q],
+                                               const float (&qy)[Q], const float (&qz)[Q], const float (&bd)[Q],
+                                               const int (&bt)[Q], unsigned selbits, int count, const float (&px)[Q],
+                                               const float (&py)[Q], const float (&pz)[Q], float (&g)[kGradN], short* ws) {
+  const int rot = threadIdx.x & (kSub - 1);
+#pragma unroll
+  for (int i = 0; i < kGradN; ++i) g[i] = 0.f;
   float R[9], T[3];
   if constexpr (DIR == 0) {
 #pragma unroll
@@ -223,13 +269,11 @@ __device__ __forceinline__ void epilogue_metric(const Smem& sm, const float4* __
   }
 #pragma unroll
   for (int k = 0; k < Q; ++k) {
-    const float bd = best[k][MET];
     int jn;
-    const float4 nn = recover_nn<MET, kRescanBatch, true>(refs + btile[k][MET] * kSub, qx[k], qy[k], qz[k], bd, rot, jn);
-    if (ws && pt_index<BLOCK, Q, OWN>(k) < count) ws[pt_index<BLOCK, Q, OWN>(k)] = (short)(btile[k][MET] * kSub + jn);
-    if (sel[k]) {
-      // no finite distance (NaN pose from an earlier sqrt'(0)): torch's min/topk/sqrt chain yields NaN, not inf
-      const float s = (bd < INFINITY) ? sqrtf(bd) : NAN;
+    const float4 nn = recover_nn<MET, kRescanBatch, true>(refs + bt[k] * kSub, qx[k], qy[k], qz[k], bd[k], rot, jn);
+    if (ws && pt_index<BLOCK, Q, OWN>(k) < count) ws[pt_index<BLOCK, Q, OWN>(k)] = (short)(bt[k] * kSub + jn);
+    if ((selbits >> k) & 1u) {
+      const float s = (bd[k] < INFINITY) ? sqrtf(bd[k]) : NAN;
       const float inv = 1.0f / s;   // d == 0 -> inf, and 0*inf = NaN below, as torch's sqrt backward gives
       float dx, dy, dz, sx, sy, sz;
       if constexpr (DIR == 1) {
@@ -246,71 +290,125 @@ __device__ __forceinline__ void epilogue_metric(const Smem& sm, const float4* __
       if constexpr (MET == 2) dy = 0.f;
       if constexpr (MET == 3) dz = 0.f;
       const float cx = dx * inv, cy = dy * inv, cz = dz * inv;
-      acc[0] += s;
-      acc[1] += cx; acc[2] += cy; acc[3] += cz;
-      acc[4] += cx * sx; acc[5] += cx * sy; acc[6] += cx * sz;
-      acc[7] += cy * sx; acc[8] += cy * sy; acc[9] += cy * sz;
-      acc[10] += cz * sx; acc[11] += cz * sy; acc[12] += cz * sz;
+      g[0] += cx; g[1] += cy; g[2] += cz;
+      g[3] += cx * sx; g[4] += cx * sy; g[5] += cx * sz;
+      g[6] += cy * sx; g[7] += cy * sy; g[8] += cy * sz;
+      g[9] += cz * sx; g[10] += cz * sy; g[11] += cz * sz;
     }
-  }
-#pragma unroll
-  for (int i = 0; i < kAccN; ++i) acc[i] = wave_sum_to_lane63(acc[i]);
-  if ((tid & 63) == 63) {
-#pragma unroll
-    for (int i = 0; i < kAccN; ++i) red_wave[MET * kAccN + i] = acc[i];
   }
 }
 
-// Epilogue of one sweep: top-k selection for the full metric, then per metric the fused rescan + sums; ONE barrier,
-// after which threads 0..NMET*13-1 add the per-wave partial sums (in wave order) into sm.acc[(metric*2+DIR)][0..13).
+// S of every metric of one direction: per-lane sums -> wave totals parked in red[dir][wave][m*13]
+template <int BLOCK, int Q, int NMET>
+__device__ __forceinline__ void park_sqrt_sums(const float (&best)[Q][NMET], const unsigned (&selbits)[NMET], float* red_wave) {
+  float bd[Q];
+#pragma unroll
+  for (int m = 0; m < NMET; ++m) {
+#pragma unroll
+    for (int k = 0; k < Q; ++k) bd[k] = best[k][m];
+    park(lane_sqrt_sum<Q>(bd, selbits[m]), red_wave + m * kAccN);
+  }
+}
+
+// G, GP of the metrics in `mask` of one direction -> red[dir][wave][m*13 + 1 ..]; no barrier in here
 template <int BLOCK, int Q, int NMET, int DIR, int OWN>
-__device__ __forceinline__ void epilogue(const Smem& sm, const float4* __restrict__ refs, const float (&qx)[Q],
-                                         const float (&qy)[Q], const float (&qz)[Q], const float (&best)[Q][NMET],
-                                         const int (&btile)[Q][NMET], int count, int k_full, int k_view,
-                                         const float (&px)[Q], const float (&py)[Q], const float (&pz)[Q], short* ws,
-                                         int ws_stride, int& hrot HOUV_STAMP_PARAM) {
+__device__ __forceinline__ void park_grad_sums(const Smem& sm, const float4* __restrict__ refs, const float (&qx)[Q],
+                                               const float (&qy)[Q], const float (&qz)[Q], const float (&best)[Q][NMET],
+                                               const int (&btile)[Q][NMET], const unsigned (&selbits)[NMET], unsigned mask,
+                                               int count, const float (&px)[Q], const float (&py)[Q], const float (&pz)[Q],
+                                               float* red_wave, short* ws, int ws_stride) {
+  float bd[Q], g[kGradN];
+  int bt[Q];
+#define HOUV_GRAD(MET)                                                                                              \
+  if ((mask >> MET) & 1u) {                                                                                         \
+    _Pragma("unroll") for (int k = 0; k < Q; ++k) {                                                                 \
+      bd[k] = best[k][MET];                                                                                         \
+      bt[k] = btile[k][MET];                                                                                        \
+    }                                                                                                               \
+    lane_grad_sums<BLOCK, Q, MET, DIR, OWN>(sm, refs, qx, qy, qz, bd, bt, selbits[MET], count, px, py, pz, g,       \
+                                            ws ? ws + (size_t)MET * ws_stride : nullptr);                           \
+    _Pragma("unroll") for (int i = 0; i < kGradN; ++i) park(g[i], red_wave + MET * kAccN + 1 + i);                  \
+  }
+  HOUV_GRAD(0)
+  if constexpr (NMET == 4) {
+    HOUV_GRAD(1)
+    HOUV_GRAD(2)
+    HOUV_GRAD(3)
+  }
+#undef HOUV_GRAD
+}
+
+// cross-wave sums (wave order) of the parked partials into sm.acc[(metric*2+dir)][..]; call after a barrier
+template <int BLOCK, int NMET>
+__device__ __forceinline__ void final_sums(const Smem& sm, int dir, bool want_s, unsigned grad_mask) {
   constexpr int NW = BLOCK / 64;
   const int tid = threadIdx.x;
-  bool valid[Q], sel0[Q];
-  unsigned key[Q];
+  if (tid < NMET * kAccN) {
+    const int m = tid / kAccN, i = tid % kAccN;
+    if ((i == 0) ? want_s : (((grad_mask >> m) & 1u) != 0u)) {
+      const float* r = sm.red + (size_t)dir * NW * kRedStride + tid;
+      float a = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) a += r[w * kRedStride];
+      sm.acc[(m * 2 + dir) * kAccStride + i] = a;
+    }
+  }
+}
+
+// which direction wins each metric's min: bit m set = direction 1 (over the moved points).  The rule of the scalar tail
+// (torch.min(cat([first, second])): first wins ties), evaluated by every thread on the same LDS values.
+template <int NMET>
+__device__ __forceinline__ unsigned picked_direction(const Smem& sm, int k_full, int k_view) {
+  unsigned pick = 0u;
+#pragma unroll
+  for (int m = 0; m < NMET; ++m) {
+    const float kk = (float)((m == 0) ? k_full : k_view);
+    const float cd0 = sm.acc[(m * 2 + 0) * kAccStride] / kk, cd1 = sm.acc[(m * 2 + 1) * kAccStride] / kk;
+    pick |= (cd0 <= cd1) ? 0u : (1u << m);
+  }
+  return pick;
+}
+
+// Mis-prediction repair (rare): metric MET's gradient flows through direction A, but A's rescans were skipped because the
+// previous iteration's winner was B and A's sweep state is gone.  Redo A for this one metric: moved points, single-metric
+// sweep (bit-identical minima and sub-tiles: same expression tree, same tie rule), selection, rescan, sums.
+template <int BLOCK, int Q, int MET, int OWN>
+__device__ __forceinline__ void repair_direction_a(const Smem& sm, const float* __restrict__ src, int N, int mpad, int k_sel,
+                                                   int& hrot, float* red_wave) {
+  float sx[Q], sy[Q], sz[Q], mx[Q], my[Q], mz[Q];
+  float R[9], T[3];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) R[i] = sm.pose[i];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) T[i] = sm.pose[9 + i];
 #pragma unroll
   for (int k = 0; k < Q; ++k) {
-    valid[k] = pt_index<BLOCK, Q, OWN>(k) < count;
-    key[k] = valid[k] ? __float_as_uint(best[k][0]) : 0xFFFFFFFFu;
-    sel0[k] = valid[k];
+    const int i = pt_index<BLOCK, Q, OWN>(k);
+    const bool ok = i < N;
+    sx[k] = ok ? src[i * 3 + 0] : 0.f;
+    sy[k] = ok ? src[i * 3 + 1] : 0.f;
+    sz[k] = ok ? src[i * 3 + 2] : 0.f;
+    mx[k] = __builtin_fmaf(sz[k], R[2], __builtin_fmaf(sy[k], R[1], sx[k] * R[0])) + T[0];
+    my[k] = __builtin_fmaf(sz[k], R[5], __builtin_fmaf(sy[k], R[4], sx[k] * R[3])) + T[1];
+    mz[k] = __builtin_fmaf(sz[k], R[8], __builtin_fmaf(sy[k], R[7], sx[k] * R[6])) + T[2];
   }
-  if (k_full < count) select_smallest<BLOCK, Q>(key, k_full, sm.hist, sm.ctl, sel0, hrot);
-  HOUV_STAMP(9);
-  float* red_wave = sm.red + ((size_t)DIR * NW + (tid >> 6)) * kRedStride;
-  epilogue_metric<BLOCK, Q, NMET, 0, DIR, OWN>(sm, refs, qx, qy, qz, best, btile, sel0, count, px, py, pz, red_wave, ws);
-  if constexpr (NMET == 4) {
-    // the view terms take all points (k_view == count in every caller; a smaller k_view selects per view metric)
-    bool selv[Q];
-#define HOUV_EPI(MET)                                                                                              \
-    {                                                                                                              \
-      _Pragma("unroll") for (int k = 0; k < Q; ++k) {                                                              \
-        selv[k] = valid[k];                                                                                        \
-        key[k] = valid[k] ? __float_as_uint(best[k][MET]) : 0xFFFFFFFFu;                                           \
-      }                                                                                                            \
-      if (k_view < count) select_smallest<BLOCK, Q>(key, k_view, sm.hist, sm.ctl, selv, hrot);                     \
-      epilogue_metric<BLOCK, Q, NMET, MET, DIR, OWN>(sm, refs, qx, qy, qz, best, btile, selv, count, px, py, pz,   \
-                                                     red_wave, ws ? ws + (size_t)MET * ws_stride : nullptr);       \
-    }
-    HOUV_EPI(1)
-    HOUV_EPI(2)
-    HOUV_EPI(3)
-#undef HOUV_EPI
-  }
-  HOUV_STAMP(8);
-  __syncthreads();
-  if (tid < NMET * kAccN) {
-    const float* r = sm.red + (size_t)DIR * NW * kRedStride + tid;
-    float a = 0.f;
+  float bd[Q];
+  int bt[Q];
+  sweep_one<Q, MET>(sm.tgt, mpad / kSub, mx, my, mz, bd, bt);
+  bool sel[Q];
+  unsigned key[Q], bits = 0u;
 #pragma unroll
-    for (int w = 0; w < NW; ++w) a += r[w * kRedStride];
-    sm.acc[((tid / kAccN) * 2 + DIR) * kAccStride + (tid % kAccN)] = a;
+  for (int k = 0; k < Q; ++k) {
+    sel[k] = pt_index<BLOCK, Q, OWN>(k) < N;
+    key[k] = sel[k] ? __float_as_uint(bd[k]) : 0xFFFFFFFFu;
   }
-  HOUV_STAMP(11);
+  if (k_sel < N) select_smallest<BLOCK, Q>(key, k_sel, sm.hist, sm.ctl, sel, hrot);
+#pragma unroll
+  for (int k = 0; k < Q; ++k) bits |= sel[k] ? (1u << k) : 0u;
+  float g[kGradN];
+  lane_grad_sums<BLOCK, Q, MET, 1, OWN>(sm, sm.tgt, mx, my, mz, bd, bt, bits, N, sx, sy, sz, g, nullptr);
+#pragma unroll
+  for (int i = 0; i < kGradN; ++i) park(g[i], red_wave + MET * kAccN + 1 + i);
 }
 
 // PRUNE: the exact pruned search of houv_sweep.h.  OWN: a lane owns Q/OWN chunks of OWN consecutive points (pt_index);
@@ -370,10 +468,22 @@ __global__ __launch_bounds__(BLOCK, 4) void solve_kernel(SolveArgs a) {
 #ifdef HOUV_STAMPS
   unsigned long long t_stamp_ = __builtin_readcyclecounter();
 #endif
+  constexpr int NW = BLOCK / 64;
+  constexpr unsigned kAllMet = (1u << NMET) - 1u;
+  // Gradient-direction prediction: bit m = "metric m's min was won by direction A (over the moved points) in the previous
+  // iteration".  A's rescans + G/GP sums run only for predicted-A metrics (A's sweep state is gone by the time the winner
+  // is known); B's run exactly for the metrics B wins; a metric predicted B but won by A is repaired (rare).  Results do
+  // not depend on the prediction.  The pruned kernel rescans everything: its next bounds need every NN.
+  const bool allgrad = PRUNE || a.pred_mode == 2;
+  unsigned pred_a = kAllMet;
+  float* red_a = sm.red + ((size_t)1 * NW + (tid >> 6)) * kRedStride;
+  float* red_b = sm.red + ((size_t)0 * NW + (tid >> 6)) * kRedStride;
 #pragma unroll 1
   for (int it = 0; it < a.n_iters; ++it) {
     float best[Q][NMET];
     int btile[Q][NMET];
+    if (a.pred_mode == 1) pred_a = 0u;
+    const unsigned grad_a = allgrad ? kAllMet : pred_a;
     {
       // ---- move this lane's source points, publish them as references for sweep B ----
       float sx[Q], sy[Q], sz[Q], mx[Q], my[Q], mz[Q];
@@ -411,10 +521,19 @@ __global__ __launch_bounds__(BLOCK, 4) void solve_kernel(SolveArgs a) {
         sweep<Q, NMET>(sm.tgt, mpad / kSub, mx, my, mz, best, btile);
       }
       HOUV_STAMP(1);
-      epilogue<BLOCK, Q, NMET, 1, OWN>(sm, sm.tgt, mx, my, mz, best, btile, N, a.k_full, a.k_view, sx, sy, sz, ws_a,
-                                  a.ws_stride, hrot HOUV_STAMP_ARG);
+      // ---- epilogue A: selection, S of every metric, G/GP of the predicted-A metrics; one barrier ----
+      unsigned sel[NMET];
+      select_all<BLOCK, Q, NMET, OWN>(sm, best, N, a.k_full, a.k_view, hrot, sel);
+      HOUV_STAMP(9);
+      park_sqrt_sums<BLOCK, Q, NMET>(best, sel, red_a);
+      park_grad_sums<BLOCK, Q, NMET, 1, OWN>(sm, sm.tgt, mx, my, mz, best, btile, sel, grad_a, N, sx, sy, sz, red_a, ws_a,
+                                            a.ws_stride);
+      HOUV_STAMP(8);
+      __syncthreads();
+      final_sums<BLOCK, NMET>(sm, 1, true, grad_a);
       HOUV_STAMP(2);
     }
+    unsigned pick_a;
     {
       // ---- sweep B: target -> moved ----
       float tx[Q], ty[Q], tz[Q];
@@ -433,10 +552,43 @@ __global__ __launch_bounds__(BLOCK, 4) void solve_kernel(SolveArgs a) {
         sweep<Q, NMET>(sm.mov, npad / kSub, tx, ty, tz, best, btile);
       }
       HOUV_STAMP(3);
-      epilogue<BLOCK, Q, NMET, 0, OWN>(sm, sm.mov, tx, ty, tz, best, btile, M, a.k_full, a.k_view, tx, ty, tz, ws_b,
-                                  a.ws_stride, hrot HOUV_STAMP_ARG);
+      // ---- epilogue B: selection and S first; then the winners are known to every thread ----
+      unsigned sel[NMET];
+      select_all<BLOCK, Q, NMET, OWN>(sm, best, M, a.k_full, a.k_view, hrot, sel);
+      HOUV_STAMP(9);
+      park_sqrt_sums<BLOCK, Q, NMET>(best, sel, red_b);
+      __syncthreads();
+      final_sums<BLOCK, NMET>(sm, 0, true, 0u);
+      __syncthreads();
+      pick_a = picked_direction<NMET>(sm, a.k_full, a.k_view);
+      const unsigned grad_b = allgrad ? kAllMet : (~pick_a & kAllMet);
+      park_grad_sums<BLOCK, Q, NMET, 0, OWN>(sm, sm.mov, tx, ty, tz, best, btile, sel, grad_b, M, tx, ty, tz, red_b, ws_b,
+                                            a.ws_stride);
+      HOUV_STAMP(8);
+      // ---- repair: won by A, but A's rescans were skipped ----
+      const unsigned miss = pick_a & ~grad_a & kAllMet;
+      if (miss) {
+        if (miss & 1u) repair_direction_a<BLOCK, Q, 0, OWN>(sm, src, N, mpad, a.k_full, hrot, red_a);
+        if constexpr (NMET == 4) {
+          if (miss & 2u) repair_direction_a<BLOCK, Q, 1, OWN>(sm, src, N, mpad, a.k_view, hrot, red_a);
+          if (miss & 4u) repair_direction_a<BLOCK, Q, 2, OWN>(sm, src, N, mpad, a.k_view, hrot, red_a);
+          if (miss & 8u) repair_direction_a<BLOCK, Q, 3, OWN>(sm, src, N, mpad, a.k_view, hrot, red_a);
+        }
+      }
+      __syncthreads();
+      final_sums<BLOCK, NMET>(sm, 0, false, grad_b);
+      if (miss) final_sums<BLOCK, NMET>(sm, 1, false, miss);
       HOUV_STAMP(4);
     }
+#ifdef HOUV_STAMPS
+    if (tid == 0) {   // prediction statistics: metric-iterations with A rescanned / won by A / repaired / total
+      atomicAdd(&g_stamp[12], (unsigned long long)__popc(grad_a));
+      atomicAdd(&g_stamp[13], (unsigned long long)__popc(pick_a));
+      atomicAdd(&g_stamp[14], (unsigned long long)__popc(pick_a & ~grad_a & kAllMet));
+      atomicAdd(&g_stamp[15], (unsigned long long)NMET);
+    }
+#endif
+    pred_a = pick_a;
     __syncthreads();
     HOUV_STAMP(5);
 
@@ -625,7 +777,10 @@ static int solve_dispatch(const float* src, const float* tgt, int P, int N, int 
   }
   SolveArgs a{src, tgt, P, N, M, K, state, steps_done, n_iters, angle_base, trans_mode, f64_params, k_full, k_view,
               lr, beta1, beta2, eps, loss_scale, out_score, out_loss, out_R, out_T, out_grad, out_cd, nn_ws, ws_valid,
-              ws_stride};
+              ws_stride, 0};
+  if (const char* e = getenv("HOUV_SOLVE_PREDICT")) {   // diagnostics: "b" = always predict B (repair path), "all" = rescan everything
+    a.pred_mode = (e[0] == 'b') ? 1 : ((e[0] == 'a') ? 2 : 0);
+  }
   hipStream_t s = (hipStream_t)stream;
   const int mx = N > M ? N : M;
   int block = 0, q = 0;

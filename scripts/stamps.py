@@ -32,3 +32,4 @@ for views in (True, False):
         print(f"   {n:10s} {100*x/tot:5.1f} %   {y/1e3:8.1f} kcycles per wave-iteration")
     for n, i in (("  epi:select", 9), ("  epi:rescan+sums+wave-reduce", 8), ("  epi:barrier+final-sum", 11)):
         print(f"   {n:16s} {per[i]/1e3:8.1f} kcycles per wave-iteration (all metrics, both directions)")
+    print(f"   prediction: A rescanned {v[12]/v[15]:.3f}, won by A {v[13]/v[15]:.3f}, repaired {v[14]/v[15]:.4f} of the metric-iterations")

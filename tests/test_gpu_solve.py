@@ -371,6 +371,40 @@ def test_pruned_search_is_bit_identical_to_brute_force(dev, N, M, views, f64, tm
         assert torch.equal(st, st_ref), chunk
 
 
+@pytest.mark.parametrize("N,views,f64,tm,pruned", [(2048, True, False, 0, False), (600, True, False, 0, False),
+                                                    (1000, False, True, 1, False), (300, True, False, 0, True)])
+def test_gradient_direction_prediction_does_not_change_results(dev, monkeypatch, N, views, f64, tm, pruned):
+    """Since round 2 the exact-NN rescans and the G / GP sums run only for the direction that wins each metric's min: A's
+    for the metrics A won in the PREVIOUS iteration (its sweep state is gone when the winner is known), B's for the
+    metrics B wins, and a metric predicted B but won by A is repaired by redoing A for that one metric.  None of this may
+    change a bit: the normal run, a run that always predicts B (every A-win takes the repair path) and a run that rescans
+    everything (HOUV_SOLVE_PREDICT, a diagnostic switch of the library) must agree exactly -- scores, losses, poses,
+    gradients, the 8 Chamfer terms and the optimiser state after 40 iterations in chunks of 50 and of 7."""
+    from houv_amd import solver, synthetic
+    P, K = 3, 26
+    src, tgt, _ = synthetic.make_pairs(P, N, seed=41)
+    src, tgt = solver.morton_sort(src.to(dev)), solver.morton_sort(tgt.to(dev))
+    p0 = solver.houv_init_params(P * K) if not f64 else np.random.default_rng(2).standard_normal((P * K, 8))
+    kw = dict(angle_base=0, trans_mode=tm, use_views=views, f64_params=f64, lr=0.1 if f64 else 0.01, want_grad=True,
+              want_cd=True, pruned=pruned)
+    runs = {}
+    for mode, chunk in ((None, 50), ("b", 50), ("all", 50), (None, 7), ("b", 7)):
+        if mode is None:
+            monkeypatch.delenv("HOUV_SOLVE_PREDICT", raising=False)
+        else:
+            monkeypatch.setenv("HOUV_SOLVE_PREDICT", mode)
+        runs[(mode, chunk)] = solver.run_stage(src, tgt, p0, K, 40, iters_per_launch=chunk, **kw)
+    monkeypatch.delenv("HOUV_SOLVE_PREDICT", raising=False)
+    ref, st_ref = runs[(None, 50)]
+    for key, (out, st) in runs.items():
+        for name in ("score", "loss", "R", "T", "grad", "cd"):
+            assert torch.equal(out[name], ref[name]), (key, name)
+        assert torch.equal(st, st_ref), key
+    # both directions do win somewhere in this workload, i.e. the three modes really exercised different code
+    picked_a = (ref["cd"][:, 0::2] > ref["cd"][:, 1::2]) if views else (ref["cd"][:, 0:1] > ref["cd"][:, 1:2])
+    assert bool(picked_a.any()) and bool((~picked_a).any())
+
+
 def test_solve_twin_end_to_end_32_pairs_vs_reference(golden, dev):
     """G14: the REAL reference's ``train_utils.solve`` (test.py:64's path: 500 iterations, lr 0.1, float64 leaves from the
     harness-seeded global numpy RNG, retry stages) on 32 synthetic 128-pt pairs, K=26.  At lr 0.1 the trajectories are
