@@ -159,3 +159,22 @@ def test_train_houv_driver_reads_the_val_file(tmp_path, monkeypatch, cpu_as_cuda
     np.testing.assert_array_equal(torch.cat([s[1] for s in seen]).numpy(), E["val__rotated_tgt"])
     np.testing.assert_array_equal(torch.cat([s[2] for s in seen]).numpy(), E["val__transforms"])
     assert res["RotE"] == 0 and res["MSE"] < 1e-6            # the ground-truth transform has zero rmse_loss against itself
+
+
+def test_train_icp_driver_reads_the_val_file(tmp_path, monkeypatch, cpu_as_cuda):
+    from houv_amd.drivers import train_icp as drv
+    seen = []
+
+    def fake_icp(src, tgt, init, thr, max_it):
+        seen.append((src.clone(), None if init is None else init.clone(), thr, max_it))
+        out = torch.eye(4).expand(src.shape[0], 4, 4).clone()
+        return out
+    monkeypatch.setattr(drv, "icp_refine", fake_icp)
+    res = drv.main(["-c", _cfg(tmp_path), "--init", "tutorial"])
+    assert [s[0].shape[0] for s in seen] == [5, 5, 2] and seen[0][2:] == (0.02, 500)                 # train_ICP.py:136,151
+    np.testing.assert_allclose(seen[0][1][0].numpy(), drv.TUTORIAL_INIT)                              # :138-141
+    np.testing.assert_array_equal(torch.cat([s[0] for s in seen]).numpy(), E["val__rotated_src"])
+    assert set(res) == {"RotE", "transE", "MSE"}
+    seen.clear()
+    drv.main(["-c", _cfg(tmp_path), "--init", "identity"])
+    assert seen[0][1] is None

@@ -68,3 +68,15 @@ def test_test_driver_results_h5_equal_direct_solve(tmp_path):
     res, out = test_drv.main(["-c", _cfg(tmp_path, 5), "--kernel", "26", "--iters", "15"])
     np.testing.assert_array_equal(res, _direct_solve(E["test__rotated_src"], E["test__rotated_tgt"], 5, 26, 15))
     assert np.array_equal(hio.load_results(out), res) and res.shape == (12, 4, 4) and np.all(res[:, 3, :] == 0)
+
+
+def test_train_icp_driver(tmp_path):
+    """train_ICP.py:100-200 mirror on the val file: the reference's fixed tutorial initialisation (a 31-degree rotation) is
+    a poor start for most pairs; started from HOUV's answer ICP must not be worse than HOUV alone and must beat the tutorial start."""
+    from houv_amd.drivers import train_icp, train_houv
+    tut = train_icp.main(["-c", _cfg(tmp_path, 4), "--init", "tutorial"])
+    hv = train_houv.main(["-c", _cfg(tmp_path, 4), "--kernel", "26", "--iters", "80"])
+    ref = train_icp.main(["-c", _cfg(tmp_path, 4), "--init", "houv", "--kernel", "26", "--iters", "80"])
+    for r in (tut, hv, ref):
+        assert np.isfinite(list(r.values())).all()
+    assert ref["RotE"] <= hv["RotE"] + 1.0 and ref["RotE"] < tut["RotE"]
