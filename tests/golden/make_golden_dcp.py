@@ -36,7 +36,12 @@ def main():
     net.eval()
     rng = np.random.default_rng(77)
     out = {}
-    for name, (B, N) in {"small": (2, 48), "mid": (2, 256)}.items():
+    cases = {"small": (2, 48), "mid": (2, 256)}
+    big = len(sys.argv) > 1 and sys.argv[1] == "2048"     # `make_golden_dcp.py 2048`: BASELINE configs[4]'s cloud size -> g19
+    if big:
+        cases = {"full": (1, 2048)}
+        rng = np.random.default_rng(2048)
+    for name, (B, N) in cases.items():
         pairs = [mg.synth_pair(rng, N, 45) for _ in range(B)]
         src = torch.tensor(np.stack([p[0] for p in pairs]))
         tgt = torch.tensor(np.stack([p[1] for p in pairs]))
@@ -56,6 +61,10 @@ def main():
                         f"{name}_ptr_tgt": pt.numpy()})
         else:                    # a strided sample of the embeddings at the larger size
             out.update({f"{name}_emb_src_s": es.numpy()[:, ::8, ::8], f"{name}_ptr_tgt_s": pt.numpy()[:, ::8, ::8]})
+    if big:
+        np.savez_compressed(f"{OUT}/g19_dcp2048.npz", **out)
+        print("wrote g19_dcp2048.npz")
+        return
     # PointNet embedding (dcp.py:246-266) with its own seeded weights
     pn = dcp.PointNet(512)
     pstate = dcp_weights.make_pointnet_state(99)

@@ -138,6 +138,29 @@ def test_model_vs_reference_golden(golden, dev):
     np.testing.assert_allclose(es.transpose(1, 2).cpu().numpy()[:, ::8, ::8], g["mid_emb_src_s"], atol=2e-4, rtol=1e-4)
 
 
+def test_model_vs_reference_golden_2048_points(golden, dev):
+    """G19: the reference's dcp.py on ONE 2048x2048-point pair -- BASELINE configs[4]'s cloud size, the
+    size bench.py --dcp runs -- with the seeded weights: k-NN sets of the DGCNN graph, a strided sample of the embeddings
+    and of the pointer output, the SVD head's (R, t) and the final T_12 (`tests/golden/make_golden_dcp.py 2048`)."""
+    from houv_amd import ops
+    g = golden("g19_dcp2048.npz")
+    net = _model(dev)
+    s, t = T(g["full_src"]).to(dev), T(g["full_tgt"]).to(dev)
+    assert s.shape == (1, 2048, 3)
+    idx = ops.knn(s, 20).cpu().long()
+    same = (idx.sort(-1)[0] == T(g["full_knn_src"]).long().sort(-1)[0]).all(-1)
+    assert same.float().mean() > 0.995            # neighbour SETS (fp32 near-ties at the 20th place aside)
+    with torch.no_grad():
+        es, et = net.emb_nn(s), net.emb_nn(t)
+        np.testing.assert_allclose(es.transpose(1, 2).cpu().numpy()[:, ::8, ::8], g["full_emb_src_s"], atol=5e-4, rtol=1e-3)
+        pt = net.pointer.model(es, et, add_to=torch.zeros_like(et))
+        np.testing.assert_allclose(pt.transpose(1, 2).cpu().numpy()[:, ::8, ::8], g["full_ptr_tgt_s"], atol=2e-3, rtol=2e-3)
+        T12 = net(s, t)
+    np.testing.assert_allclose(T12.cpu().numpy(), g["full_T12"], atol=3e-3)
+    np.testing.assert_allclose(T12[:, :3, :3].cpu().numpy(), g["full_R"], atol=3e-3)
+    np.testing.assert_allclose(T12[:, :3, 3].cpu().numpy(), g["full_t"], atol=3e-3)
+
+
 def test_model_with_T_gt_returns_reference_tuple(dev):
     from houv_amd import synthetic
     net = _model(dev)
