@@ -237,7 +237,7 @@ def bench_dcp(args, dev, world, rank):
                                f"batch {P}/GPU (BASELINE configs[4])", "pairs_per_gpu": P, "points": args.points,
                    "parallelism": f"dp{world}"},
         "quality": {"mean_houv_loss_of_dcp_answer": float(np.mean(losses[-args.steps:]))},
-        "roofline": {"kernel": "houv::gemm_f32_kernel (v_mfma_f32_32x32x2_f32)", "bound": "mfma",
+        "roofline": {"kernel": "houv::gemm_f32_kernel + houv::attention_f32_kernel (v_mfma_f32_32x32x2_f32)", "bound": "mfma",
                      "achieved": g_fl / (g_ms * 1e-3) / 1e12, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": g_fl / (g_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, "traffic": None, "launches": len(log),
                      "avg_launch_ms": g_ms / max(len(log), 1), "kernel_time_share": g_ms * 1e-3 / dt},

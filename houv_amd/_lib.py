@@ -38,6 +38,8 @@ _SIGNATURES = {
     "houv_gemm_f32": (ctypes.c_int, [_c_f, _c_f, _c_f, _int, _int, _int, _int, _int, _int, _int, _int, _int] +
                       [ctypes.c_longlong] * 6 + [_flt, _c_f, _c_f, _c_f, _int, ctypes.c_longlong, ctypes.c_longlong,
                                                  _int, _c_f]),
+    "houv_attention_f32": (ctypes.c_int, [_c_f, _c_f, _c_f, _c_f, _int, _int, _int, _int, _int, _int, _int, _int, _int] +
+                           [ctypes.c_longlong] * 4 + [_flt, _c_f]),
     "houv_layernorm": (ctypes.c_int, [_c_f, ctypes.c_longlong, _int, _c_f, _c_f, _flt, _c_f, _c_f, _c_f]),
     "houv_softmax_rows": (ctypes.c_int, [_c_f, ctypes.c_longlong, _int, _c_f]),
     "houv_softmax_corr": (ctypes.c_int, [_c_f, _int, _int, _int, _c_f, _c_f, _c_f]),

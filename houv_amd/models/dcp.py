@@ -78,11 +78,15 @@ class _Attention(nn.Module):
         Q = ops.gemm(q_in.reshape(P * Nq, D_MODEL), lq.weight, shift=lq.bias).view(P, Nq, N_HEADS, dk)
         Kt = ops.gemm(kv_in.reshape(P * Nk, D_MODEL), lk.weight, shift=lk.bias).view(P, Nk, N_HEADS, dk)
         V = ops.gemm(kv_in.reshape(P * Nk, D_MODEL), lv.weight, shift=lv.bias).view(P, Nk, N_HEADS, dk)
-        # scores[p,h] = Q_ph K_ph^T / sqrt(dk): per-head operands are strided views (row stride 512), no copies
-        scores = ops.gemm(Q.permute(0, 2, 1, 3), Kt.permute(0, 2, 1, 3), trans_b=True, alpha=1.0 / math.sqrt(dk))
-        ops.softmax_rows_(scores)
-        ctx = torch.empty((P, Nq, N_HEADS, dk), dtype=torch.float32, device=q_in.device)
-        ops.gemm(scores, V.permute(0, 2, 1, 3), ctx.permute(0, 2, 1, 3), trans_b=False)
+        if ops.FUSED_ATTENTION:
+            # softmax(Q K^T / sqrt(dk)) V per head in one kernel: the [P,4,Nq,Nk] scores never reach HBM
+            ctx = ops.attention(Q, Kt, V, 1.0 / math.sqrt(dk))
+        else:
+            # scores[p,h] = Q_ph K_ph^T / sqrt(dk): per-head operands are strided views (row stride 512), no copies
+            scores = ops.gemm(Q.permute(0, 2, 1, 3), Kt.permute(0, 2, 1, 3), trans_b=True, alpha=1.0 / math.sqrt(dk))
+            ops.softmax_rows_(scores)
+            ctx = torch.empty((P, Nq, N_HEADS, dk), dtype=torch.float32, device=q_in.device)
+            ops.gemm(scores, V.permute(0, 2, 1, 3), ctx.permute(0, 2, 1, 3), trans_b=False)
         out = ops.gemm(ctx.view(P * Nq, D_MODEL), lo.weight, shift=lo.bias, residual=residual.reshape(P * Nq, D_MODEL))
         return out.view(P, Nq, D_MODEL)
 

@@ -282,6 +282,38 @@ def gemm(A, B, C=None, *, trans_b=True, alpha=1.0, scale=None, shift=None, resid
     return C
 
 
+# set to False to route models.dcp's attention through gemm -> softmax_rows -> gemm (the [P,H,Nq,Nk] scores materialised)
+FUSED_ATTENTION = True
+
+
+def attention(Q, K, V, scale):
+    """Fused multi-head attention (dcp.py:26-32): Q[P,Nq,H,128], K/V[P,Nk,H,128] (views of token-major [P,N,H*128] buffers)
+    -> context[P,Nq,H,128] = softmax(Q K^T * scale) V per head; the scores never reach HBM (houv_attention_f32)."""
+    _lib.require_gpu_any(Q, K, V)
+    P, Nq, H, dk = Q.shape
+    Nk = K.shape[1]
+    if dk != 128 or tuple(K.shape) != (P, Nk, H, dk) or tuple(V.shape) != (P, Nk, H, dk):
+        raise _lib.HouvHipError("attention: expected Q[P,Nq,H,128], K[P,Nk,H,128], V[P,Nk,H,128]")
+    for t in (Q, K, V):
+        if t.stride(3) != 1 or t.stride(2) != dk:
+            raise _lib.HouvHipError("attention: heads must be contiguous 128-float slices of a token row")
+    out = torch.empty((P, Nq, H, dk), dtype=_F32, device=Q.device)
+    if GEMM_LOG is not None:
+        ev0 = torch.cuda.Event(enable_timing=True)
+        ev1 = torch.cuda.Event(enable_timing=True)
+        ev0.record(torch.cuda.current_stream(Q.device))
+    with torch.cuda.device(Q.device):
+        ok = _lib.load().houv_attention_f32(ctypes_ptr(Q), ctypes_ptr(K), ctypes_ptr(V), ctypes_ptr(out), P, H, Nq, Nk, dk,
+                                            Q.stride(1), K.stride(1), V.stride(1), out.stride(1), Q.stride(0) if P else 0,
+                                            K.stride(0) if P else 0, V.stride(0) if P else 0, out.stride(0) if P else 0,
+                                            float(scale), _lib.stream_of(Q))
+    _lib.check(ok, "houv_attention_f32")
+    if GEMM_LOG is not None:
+        ev1.record(torch.cuda.current_stream(Q.device))
+        GEMM_LOG.append((ev0, ev1, 4.0 * P * H * Nq * Nk * dk))
+    return out
+
+
 def layernorm(x, a, b, eps=1e-6, residual=None):
     _lib.require_gpu(x, a, b, residual)
     for t, n in ((x, "x"), (a, "a"), (b, "b"), (residual, "residual")):

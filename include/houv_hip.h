@@ -161,6 +161,13 @@ int houv_gemm_f32(const float* A, const float* B, float* C, int M, int N, int K,
                   long long sCo, long long sCi, float alpha, const float* scale_or_null, const float* shift_or_null,
                   const float* residual_or_null, int ldr, long long sRo, long long sRi, int relu, void* stream);
 
+/* dcp.py:26-32 `attention` of MultiHeadedAttention (:198-229), fused: O = softmax(Q K^T * scale) V per (pair, head); the
+ * [Nq,Nk] scores stay on chip (online softmax).  Token-major operands: head h of row n of pair p starts at
+ * X + p*sX + n*ldX + h*dk.  dk must be 128 (DCP: 512 / 4 heads); strides multiples of 4 floats, pointers 16-byte aligned. */
+int houv_attention_f32(const float* Q, const float* K, const float* V, float* O, int P, int H, int Nq, int Nk, int dk,
+                       int ldq, int ldk, int ldv, int ldo, long long sQ, long long sK, long long sV, long long sO,
+                       float scale, void* stream);
+
 /* dcp.py:144-154 LayerNorm: out = a*(x-mean)/(std+eps)+b over the last dim D (torch.std: unbiased) [+ residual]. */
 int houv_layernorm(const float* x, long long rows, int D, const float* a, const float* b, float eps,
                    const float* residual_or_null, float* out, void* stream);

@@ -28,12 +28,17 @@ print(f"attn QK^T P=8: {t:.3f} ms {2.0*P*H*Nq*Nq*128/t/1e9:.1f} TFLOP/s; write {
 t = timed(lambda: ops.softmax_rows_(S)); print(f"softmax: {t:.3f} ms {2*P*H*Nq*Nq*4/t/1e6:.0f} GB/s")
 t = timed(lambda: ops.gemm(S, V.permute(0, 2, 1, 3), ctx.permute(0, 2, 1, 3), trans_b=False))
 print(f"attn PV   P=8: {t:.3f} ms {2.0*P*H*Nq*Nq*128/t/1e9:.1f} TFLOP/s; read {P*H*Nq*Nq*4/t/1e6:.0f} GB/s")
+t = timed(lambda: ops.attention(Q, Kt, V, 0.1))
+print(f"fused attention P=8: {t:.3f} ms {4.0*P*H*Nq*Nq*128/t/1e9:.1f} TFLOP/s (QK^T + softmax + PV in one kernel)")
 x = torch.rand(16, 2048, 3, device=dev)
 t = timed(lambda: ops.knn(x, 20)); print(f"knn20 B=16 N=2048: {t:.3f} ms")
 net = Model(None, pairs_per_chunk=8).to(dev)
 src, tgt, _ = synthetic.make_pairs(32, 2048, seed=2)
 src, tgt = src.to(dev), tgt.to(dev)
-t = timed(lambda: net(src, tgt), n=3)
+for fused in (False, True):
+    ops.FUSED_ATTENTION = fused
+    t = timed(lambda: net(src, tgt), n=3)
+    print(f"fused_attention={fused}: DCP forward 32 pairs x 2048 pts: {t:.1f} ms -> {32/(t/1e3):.1f} pairs/s")
 flop_pair = 2 * (2048*20*(64*64+64*128+128*256)*2 + 2048*512*512*2) + 2 * (  # two clouds DGCNN; two transformer passes:
     3 * (4*2048*512*512*2 + 2*2048*2048*512*2) + 2*2 * 2048*512*1024*2) + 2048*2048*512*2
 print(f"DCP forward 32 pairs x 2048 pts: {t:.1f} ms -> {32/(t/1e3):.1f} pairs/s, ~{flop_pair*32/t/1e9:.1f} TFLOP/s of GEMM work")

@@ -108,6 +108,38 @@ def _model(dev):
     return net.to(dev)
 
 
+@pytest.mark.parametrize("P,Nq,Nk", [(2, 300, 77), (1, 2048, 2048), (3, 128, 31), (2, 33, 500), (1, 1, 1)])
+def test_fused_attention_vs_float64(dev, P, Nq, Nk):
+    """houv_attention_f32 (dcp.py:26-32 fused: the scores never reach HBM) against torch in float64 on the same operands,
+    ragged sizes (key-block tails, query-block tails) included; operands are the strided per-head views the model passes."""
+    from houv_amd import ops
+    H, dk = 4, 128
+    gen = torch.Generator().manual_seed(P * 1000 + Nq + Nk)
+    q = torch.randn(P, Nq, H * dk, generator=gen).to(dev)
+    k = torch.randn(P, Nk, H * dk, generator=gen).to(dev)
+    v = torch.randn(P, Nk, H * dk, generator=gen).to(dev)
+    scale = 1.0 / np.sqrt(dk)
+    out = ops.attention(q.view(P, Nq, H, dk), k.view(P, Nk, H, dk), v.view(P, Nk, H, dk), scale)
+    qd, kd, vd = (t.double().view(P, -1, H, dk).permute(0, 2, 1, 3) for t in (q, k, v))
+    ref = (torch.softmax(qd @ kd.transpose(-1, -2) * scale, dim=-1) @ vd).permute(0, 2, 1, 3)
+    np.testing.assert_allclose(out.cpu().numpy(), ref.float().cpu().numpy(), rtol=2e-5, atol=2e-5)
+    # large-magnitude logits: the running maximum must keep exp() in range
+    out2 = ops.attention((q * 30).view(P, Nq, H, dk), k.view(P, Nk, H, dk), v.view(P, Nk, H, dk), scale)
+    ref2 = (torch.softmax((qd * 30) @ kd.transpose(-1, -2) * scale, dim=-1) @ vd).permute(0, 2, 1, 3)
+    assert bool(torch.isfinite(out2).all())
+    np.testing.assert_allclose(out2.cpu().numpy(), ref2.float().cpu().numpy(), rtol=1e-4, atol=1e-4)
+
+
+def test_model_is_the_same_with_and_without_fused_attention(dev, monkeypatch):
+    from houv_amd import ops, synthetic
+    net = _model(dev)
+    src, tgt, _ = synthetic.make_pairs(2, 300, seed=12)
+    a = net(src.to(dev), tgt.to(dev))
+    monkeypatch.setattr(ops, "FUSED_ATTENTION", False)
+    b = net(src.to(dev), tgt.to(dev))
+    np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), atol=2e-4)
+
+
 def test_state_dict_names_equal_reference():
     from houv_amd.models.dcp import Model
     mine = {k for k in Model(None).state_dict() if not k.endswith("num_batches_tracked") and k != "head.reflect"}
