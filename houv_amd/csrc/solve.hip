@@ -48,6 +48,7 @@ struct SolveArgs {
   int ws_stride;
   int pred_mode;     // diagnostics (HOUV_SOLVE_PREDICT): 0 normal; 1 always predict direction B (every A-win takes the
                      // repair path); 2 rescan everything (no skipping: the round-1 epilogue's work)
+  int ws_refresh;    // pruned mode: every ws_refresh-th iteration rescans everything (refreshes every remembered NN)
 };
 
 #ifdef HOUV_STAMPS
@@ -473,8 +474,9 @@ __global__ __launch_bounds__(BLOCK, 4) void solve_kernel(SolveArgs a) {
   // Gradient-direction prediction: bit m = "metric m's min was won by direction A (over the moved points) in the previous
   // iteration".  A's rescans + G/GP sums run only for predicted-A metrics (A's sweep state is gone by the time the winner
   // is known); B's run exactly for the metrics B wins; a metric predicted B but won by A is repaired (rare).  Results do
-  // not depend on the prediction.  The pruned kernel rescans everything: its next bounds need every NN.
-  const bool allgrad = PRUNE || a.pred_mode == 2;
+  // not depend on the prediction.  The pruned kernel's bounds are distances to REMEMBERED nearest neighbours (nn_ws): any
+  // remembered point gives a valid, attained bound, so a skipped rescan only leaves an older neighbour in place (a
+  // slightly looser bound); every ws_refresh-th iteration rescans everything to keep them fresh.
   unsigned pred_a = kAllMet;
   float* red_a = sm.red + ((size_t)1 * NW + (tid >> 6)) * kRedStride;
   float* red_b = sm.red + ((size_t)0 * NW + (tid >> 6)) * kRedStride;
@@ -483,6 +485,8 @@ __global__ __launch_bounds__(BLOCK, 4) void solve_kernel(SolveArgs a) {
     float best[Q][NMET];
     int btile[Q][NMET];
     if (a.pred_mode == 1) pred_a = 0u;
+    const bool allgrad = a.pred_mode == 2 || (PRUNE && (a.ws_refresh <= 1 || ((a.steps_done + it) % a.ws_refresh) == 0 ||
+                                                        (a.ws_valid == 0 && it == 0)));
     const unsigned grad_a = allgrad ? kAllMet : pred_a;
     {
       // ---- move this lane's source points, publish them as references for sweep B ----
@@ -777,7 +781,10 @@ static int solve_dispatch(const float* src, const float* tgt, int P, int N, int 
   }
   SolveArgs a{src, tgt, P, N, M, K, state, steps_done, n_iters, angle_base, trans_mode, f64_params, k_full, k_view,
               lr, beta1, beta2, eps, loss_scale, out_score, out_loss, out_R, out_T, out_grad, out_cd, nn_ws, ws_valid,
-              ws_stride, 0};
+              ws_stride, 0, 2};
+  // pruned mode refreshes every remembered NN on every 2nd iteration (same-device A/B, profiles/r02_ab_pruned_refresh.txt:
+  // 1 -> 0.988, 2 -> 0.960, 4 -> 0.963, 8 -> 0.990, never -> 1.09 us per hypothesis-iteration; results identical in all)
+  if (const char* e = getenv("HOUV_PRUNE_REFRESH")) a.ws_refresh = atoi(e);   // diagnostics
   if (const char* e = getenv("HOUV_SOLVE_PREDICT")) {   // diagnostics: "b" = always predict B (repair path), "all" = rescan everything
     a.pred_mode = (e[0] == 'b') ? 1 : ((e[0] == 'a') ? 2 : 0);
   }
