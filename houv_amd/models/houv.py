@@ -30,6 +30,18 @@ class HOUV(nn.Module):
         # quirk kept (houv.py:36,61,99): __init__ creates tran_s_cpu, forward reads tran_s (made by reset_weight)
         self.tran_s_cpu = nn.Parameter(torch.from_numpy(np.random.randn(batch_size, 1).astype(np.float32)))
 
+    @classmethod
+    def blank_like(cls, other):
+        """A module of the same kind WITHOUT touching the global numpy RNG (the constructor draws from it, houv.py:21-36):
+        the concurrent retry stages of solve_model each need their own parameter holder."""
+        self = cls.__new__(cls)
+        nn.Module.__init__(self)
+        self.batch_size, self.angle_base, self.pi = other.batch_size, other.angle_base, other.pi
+        dev = other.V_c.device
+        for name, width in (("V_c", 3), ("angle_c", 1), ("tran_c", 3), ("tran_s_cpu", 1)):
+            setattr(self, name, nn.Parameter(torch.zeros((1, width), device=dev)))
+        return self
+
     def reset_weight(self, batch_size, angle_base, seed=2021):
         self.batch_size = batch_size
         self.angle_base = angle_base
@@ -86,7 +98,10 @@ def solve_model(net, src, src_rotated, pose=None, src_ori=None, tgt_ori=None, an
     """houv.py:142-206: base-0 solve, retry of pairs with best min_1 > 0.030 at bases 1..3, ans[B,4,4]
     (row 3 all-zero), then (r_err, t_err, ans) or ``ans.cpu()`` for prefix == 'test'."""
     def stage(s, t, base):
-        return predict_model(net, s, t, kernel=kernel, num_epochs=num_epochs, angle_base=base)
+        # the retry stages may run concurrently on side streams: bases 1 and 2 get their own parameter holder, base 3
+        # (the last one the reference runs) leaves its parameters in `net` like the reference does
+        holder = net if base in (0, 3) else HOUV.blank_like(net)
+        return predict_model(holder, s, t, kernel=kernel, num_epochs=num_epochs, angle_base=base)
 
     ans, _, _ = solver.best_of_k_with_retry(stage, src, src_rotated)
     if prefix == 'test':

@@ -198,6 +198,21 @@ def run_stage(src, tgt, params, K, n_iters, *, angle_base, trans_mode, use_views
     return out, state
 
 
+# The three retry stages (angle windows 45-90 / 90-135 / 135-180 degrees) are independent solves of the same retried
+# pairs: launched on three side streams they share the GPU instead of each leaving most of it idle (a retry set of 10
+# pairs x 64 restarts is 640 workgroups on a chip that holds 512 at a time: two rounds for 1.25 rounds of work, three
+# times over).  The replacements are still applied in the reference's order 1, 2, 3.
+CONCURRENT_RETRIES = True
+_retry_streams = {}
+
+
+def _side_streams(dev):
+    key = (dev.type, dev.index)
+    if key not in _retry_streams:
+        _retry_streams[key] = [torch.cuda.Stream(device=dev) for _ in range(3)]
+    return _retry_streams[key]
+
+
 def best_of_k_with_retry(stage_fn, src, tgt):
     """houv.py:152-197 / train_utils.py:488-545.  ``stage_fn(src, tgt, base) -> (score[B,K], R[B,K,3,3], T[B,K,3])``.
     Base-0 stage; pairs whose best score is > 0.030 are re-solved in the 45-90/90-135/135-180 degree windows
@@ -209,8 +224,25 @@ def best_of_k_with_retry(stage_fn, src, tgt):
     retry = torch.nonzero(best[:, 0] > RETRY_THRESHOLD).reshape(-1)
     if retry.numel() > 0:
         s_add, t_add = src[retry], tgt[retry]
+        outs = {}
+        if CONCURRENT_RETRIES and src.is_cuda:
+            main = torch.cuda.current_stream(src.device)
+            side = _side_streams(src.device)
+            for base in range(1, 4):
+                side[base - 1].wait_stream(main)                        # s_add / t_add were produced on the main stream
+                with torch.cuda.stream(side[base - 1]):
+                    outs[base] = stage_fn(s_add, t_add, base)
+            for base in range(1, 4):
+                main.wait_stream(side[base - 1])
+                for x in outs[base]:
+                    x.record_stream(main)
+            s_add.record_stream(side[0]); s_add.record_stream(side[1]); s_add.record_stream(side[2])
+            t_add.record_stream(side[0]); t_add.record_stream(side[1]); t_add.record_stream(side[2])
+        else:
+            for base in range(1, 4):
+                outs[base] = stage_fn(s_add, t_add, base)
         for base in range(1, 4):
-            score_a, R_a, T_a = stage_fn(s_add, t_add, base)
+            score_a, R_a, T_a = outs[base]
             best_a, _ = score_a.topk(1, dim=1, largest=False, sorted=True)
             flag = torch.nonzero((best_a < best[retry]).reshape(-1)).reshape(-1)
             ge = retry[flag]

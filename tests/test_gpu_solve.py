@@ -429,3 +429,28 @@ def test_solve_twin_end_to_end_32_pairs_vs_reference(golden, dev):
     assert (np.abs(r_m - r_r) <= 5.0).mean() >= 0.6
     assert abs(r_m.mean() - r_r.mean()) <= 3.0 and abs(np.median(r_m) - np.median(r_r)) <= 1.5
     assert abs((r_m < 5).mean() - (r_r < 5).mean()) <= 0.1 and abs(t_m.mean() - t_r.mean()) <= 0.015
+
+
+def test_concurrent_retry_stages_equal_sequential_ones(dev, monkeypatch):
+    """The three retry stages of solve_model / solve are independent solves of the same retried pairs; launched on three side
+    streams (solver.CONCURRENT_RETRIES) they must give exactly what the sequential order gives, and `net` must end up with the
+    last stage's parameters either way (houv.py:168-180)."""
+    from houv_amd import solver, synthetic
+    from houv_amd.models.houv import HOUV, solve_model
+    from houv_amd.train_utils import solve
+    src, tgt, pose = synthetic.make_pairs(12, 256, seed=99)          # several pairs beyond the 0.030 threshold after 25 iterations
+    src, tgt, pose = src.to(dev), tgt.to(dev), pose.to(dev)
+    outs = {}
+    for conc in (True, False):
+        monkeypatch.setattr(solver, "CONCURRENT_RETRIES", conc)
+        net = HOUV(12 * 26, 0)
+        r, t, ans = solve_model(net, src, tgt, pose, kernel=26, num_epochs=25)
+        np.random.seed(5)
+        twin = solve(src, tgt, kernel=26, prefix='test', _iters=12)
+        outs[conc] = (ans.clone(), net.packed_params().detach().clone(), twin.clone())
+    monkeypatch.setattr(solver, "CONCURRENT_RETRIES", True)
+    for a, b in zip(outs[True], outs[False]):
+        assert torch.equal(a, b)
+    _, score, retry = solver.best_of_k_with_retry(
+        lambda s, t, base: __import__("houv_amd.models.houv", fromlist=["x"]).predict_model(HOUV.blank_like(HOUV(26, 0).to(dev)), s, t, kernel=26, num_epochs=25, angle_base=base), src, tgt)
+    assert 0 < retry.numel() < 12            # the workload really has a retry stage
