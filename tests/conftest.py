@@ -15,9 +15,10 @@ if os.path.join(ROOT, "tests") not in sys.path:
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     # the CPU oracle runs many tiny torch ops: on a box that shows hundreds of host cores the default intra-op pool is
-    # several times slower than a small one
+    # several times slower than a small one; 4 threads are as fast as 8 here (18.7 s vs 19.9 s for test_oracle_golden.py)
+    # and leave cores free -- with all 8 cores taken, any other load made the OpenMP barriers spin (5-7 minute runs)
     import torch
-    torch.set_num_threads(max(1, min(8, os.cpu_count() or 1)))
+    torch.set_num_threads(max(1, min(4, os.cpu_count() or 1)))
     # Multi-process GPU tests (tests/test_gpu_distributed.py) take their ranks from a fork SERVER that is started here,
     # before anything in this process has touched the GPU: its children are forked from a GPU-clean process and
     # initialise HIP themselves.  (Spawning -- fork + exec -- out of a process that already holds the GPU is what the
