@@ -110,7 +110,10 @@ __device__ inline Smem carve(unsigned char* base, int N, int M, int block) {
   s.red = s.acc + 8 * kAccStride;
   s.hist = reinterpret_cast<unsigned*>(s.red + 2 * nw * kRedStride);
   s.ctl = reinterpret_cast<int*>(s.hist + kHistSets * kHistBins);
-  s.tbox = reinterpret_cast<float4*>((reinterpret_cast<uintptr_t>(s.ctl + 8 + nw) + 15) & ~(uintptr_t)15);
+  // 16-byte alignment by OFFSET arithmetic on the shared segment (a pointer -> integer -> pointer round trip hides the LDS
+  // address space from the compiler: the box reads of the pruned sweep became flat_load_dwordx3 + s_waitcnt vmcnt(0))
+  const size_t box_off = ((size_t)(reinterpret_cast<unsigned char*>(s.ctl + 8 + nw) - base) + 15) & ~(size_t)15;
+  s.tbox = reinterpret_cast<float4*>(base + box_off);
   s.mbox = s.tbox + 128;
   return s;
 }
