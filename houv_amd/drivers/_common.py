@@ -8,6 +8,7 @@ import sys
 import numpy as np
 import torch
 
+from .. import io as hio
 from ..dataset import open_pairs
 
 
@@ -52,8 +53,7 @@ def loader(prefix, args, l=None, r=None, n_synthetic=None, take=None):
     if path:
         logging.info('%s split from %s', prefix, path)
     else:
-        logging.info('%s not found: running on %d MVP-shaped SYNTHETIC pairs', os.path.basename(
-            __import__('houv_amd.io', fromlist=['x']).mvp_path(prefix, args)), len(ds))
+        logging.info('%s not found: running on %d MVP-shaped SYNTHETIC pairs', hio.mvp_path(prefix, args), len(ds))
     if take is not None:
         ds = torch.utils.data.Subset(ds, [int(i) for i in take])
     dl = torch.utils.data.DataLoader(ds, batch_size=int(args.batch_size), shuffle=False, num_workers=int(args.workers))
