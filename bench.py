@@ -38,11 +38,11 @@ PEAK_CLOCK_HZ = 2.4e9        # the clock the 157.3 TFLOP/s peak is quoted at: 10
 N_SIMD = 1024
 # VALU issue slots (one slot = one full-rate wave64 instruction = 2 clk of a SIMD) the sweep spends per point pair and wave:
 #   4-metric sweep: 3 v_sub + 2 v_mul + 4 v_fma = 9 slots, 2 v_min3 at half rate = 4 slots, sub-tile tracking
-#                   (v_cmp + 2 v_cndmask per query, metric and 32 references, all half rate) 0.75            -> 13.75
-#   1-metric sweep: 3 v_sub + 1 v_mul + 2 v_fma = 6 slots, 1/2 v_min3 = 1 slot, tracking 0.1875             ->  7.1875
+#                   (v_cmp + v_cndmask per query, metric and 32 references, both half rate) 0.5              -> 13.5
+#   1-metric sweep: 3 v_sub + 1 v_mul + 2 v_fma = 6 slots, 1/2 v_min3 = 1 slot, tracking 0.125              ->  7.125
 # Only v_add/sub/mul/fma/mov issue at one wave64 instruction per 2 clk on gfx950; v_min/max/min3/med3, v_cmp, v_cndmask and
 # the integer ops take 4 (scripts/ubench/{valu_rate,misc_rate}.hip: profiles/r01_valu_rate.txt, r02_instr_rates.txt)
-SLOTS_PER_PAIR = {True: 13.75, False: 7.1875}
+SLOTS_PER_PAIR = {True: 13.5, False: 7.125}
 EXEC_FLOP_PER_PAIR = {True: 13.0, False: 8.0}     # flops the fused sweep really executes per point pair (mins not counted)
 
 

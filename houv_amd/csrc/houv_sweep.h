@@ -14,10 +14,46 @@ typedef const houv_f4v __attribute__((address_space(3))) * lds_f4;   // LDS poin
 // The brute-force sweep: for each of this lane's Q queries, min over all references of the NMET
 // squared distances, plus the id of the 32-reference sub-tile that produced each minimum.
 // ------------------------------------------------------------------------------------------------
+// One sub-tile of the sweep: out = min(in, the sub-tile's distances), per query and metric.  `in` and `out` are DIFFERENT
+// register sets (the first v_min3 of a chain is three-address: out = min3(in, a, c)), so the caller can compare out against in
+// afterwards without having saved a copy.
+template <int Q, int NMET>
+__device__ __forceinline__ void sweep_tile(const float4* __restrict__ rp, const float (&qx)[Q], const float (&qy)[Q],
+                                           const float (&qz)[Q], const float (&in)[Q][NMET], float (&out)[Q][NMET]) {
+#pragma unroll
+  for (int j = 0; j < kSub; j += 2) {
+    const float4 a = rp[j], c = rp[j + 1];
+    // keep .w "used" so the loads stay ds_read_b128 (4 LDS cycles) instead of ds_read_b96 (8)
+    asm volatile("" ::"v"(a.w), "v"(c.w));
+#pragma unroll
+    for (int k = 0; k < Q; ++k) {
+      const float ax = a.x - qx[k], ay = a.y - qy[k], az = a.z - qz[k];
+      const float cx = c.x - qx[k], cy = c.y - qy[k], cz = c.z - qz[k];
+      if constexpr (NMET == 4) {
+        const float axx = ax * ax, ayy = ay * ay, cxx = cx * cx, cyy = cy * cy;
+        const float a3 = __builtin_fmaf(ay, ay, axx), c3 = __builtin_fmaf(cy, cy, cxx);   // z dropped
+        const float a1 = __builtin_fmaf(az, az, ayy), c1 = __builtin_fmaf(cz, cz, cyy);   // x dropped
+        const float a2 = __builtin_fmaf(az, az, axx), c2 = __builtin_fmaf(cz, cz, cxx);   // y dropped
+        const float a0 = __builtin_fmaf(az, az, a3), c0 = __builtin_fmaf(cz, cz, c3);     // full
+        out[k][0] = min3f(j == 0 ? in[k][0] : out[k][0], a0, c0);
+        out[k][1] = min3f(j == 0 ? in[k][1] : out[k][1], a1, c1);
+        out[k][2] = min3f(j == 0 ? in[k][2] : out[k][2], a2, c2);
+        out[k][3] = min3f(j == 0 ? in[k][3] : out[k][3], a3, c3);
+      } else {
+        out[k][0] = min3f(j == 0 ? in[k][0] : out[k][0], metric_sqdist<0>(ax, ay, az), metric_sqdist<0>(cx, cy, cz));
+      }
+    }
+  }
+}
+
 template <int Q, int NMET>
 __device__ __forceinline__ void sweep(const float4* __restrict__ refs, int ntile, const float (&qx)[Q],
                                       const float (&qy)[Q], const float (&qz)[Q], float (&best)[Q][NMET],
                                       int (&btile)[Q][NMET]) {
+  // The running minimum is threaded through the sub-tiles, ping-ponging between two register sets: per query, metric and
+  // sub-tile the bookkeeping is one v_cmp + one v_cndmask ("did this sub-tile lower the minimum?"; strict <: the earlier
+  // sub-tile keeps ties, so the lowest index wins) instead of v_cmp + two v_cndmask -- all half-rate instructions.
+  float other[Q][NMET];
 #pragma unroll
   for (int k = 0; k < Q; ++k)
 #pragma unroll
@@ -25,44 +61,27 @@ __device__ __forceinline__ void sweep(const float4* __restrict__ refs, int ntile
       best[k][m] = INFINITY;
       btile[k][m] = 0;
     }
-  for (int t = 0; t < ntile; ++t) {
-    float tm[Q][NMET];
+  int t = 0;
+  for (; t + 1 < ntile; t += 2) {
+    sweep_tile<Q, NMET>(refs + t * kSub, qx, qy, qz, best, other);
 #pragma unroll
     for (int k = 0; k < Q; ++k)
 #pragma unroll
-      for (int m = 0; m < NMET; ++m) tm[k][m] = INFINITY;
-    const float4* rp = refs + t * kSub;
-#pragma unroll 4
-    for (int j = 0; j < kSub; j += 2) {
-      const float4 a = rp[j], c = rp[j + 1];
-      // keep .w "used" so the loads stay ds_read_b128 (4 LDS cycles) instead of ds_read_b96 (8)
-      asm volatile("" ::"v"(a.w), "v"(c.w));
+      for (int m = 0; m < NMET; ++m) btile[k][m] = (other[k][m] < best[k][m]) ? t : btile[k][m];
+    sweep_tile<Q, NMET>(refs + (t + 1) * kSub, qx, qy, qz, other, best);
 #pragma unroll
-      for (int k = 0; k < Q; ++k) {
-        const float ax = a.x - qx[k], ay = a.y - qy[k], az = a.z - qz[k];
-        const float cx = c.x - qx[k], cy = c.y - qy[k], cz = c.z - qz[k];
-        if constexpr (NMET == 4) {
-          const float axx = ax * ax, ayy = ay * ay, cxx = cx * cx, cyy = cy * cy;
-          const float a3 = __builtin_fmaf(ay, ay, axx), c3 = __builtin_fmaf(cy, cy, cxx);   // z dropped
-          const float a1 = __builtin_fmaf(az, az, ayy), c1 = __builtin_fmaf(cz, cz, cyy);   // x dropped
-          const float a2 = __builtin_fmaf(az, az, axx), c2 = __builtin_fmaf(cz, cz, cxx);   // y dropped
-          const float a0 = __builtin_fmaf(az, az, a3), c0 = __builtin_fmaf(cz, cz, c3);     // full
-          tm[k][0] = min3f(tm[k][0], a0, c0);
-          tm[k][1] = min3f(tm[k][1], a1, c1);
-          tm[k][2] = min3f(tm[k][2], a2, c2);
-          tm[k][3] = min3f(tm[k][3], a3, c3);
-        } else {
-          tm[k][0] = min3f(tm[k][0], metric_sqdist<0>(ax, ay, az), metric_sqdist<0>(cx, cy, cz));
-        }
-      }
-    }
+    for (int k = 0; k < Q; ++k)
+#pragma unroll
+      for (int m = 0; m < NMET; ++m) btile[k][m] = (best[k][m] < other[k][m]) ? t + 1 : btile[k][m];
+  }
+  if (t < ntile) {   // odd number of sub-tiles
+    sweep_tile<Q, NMET>(refs + t * kSub, qx, qy, qz, best, other);
 #pragma unroll
     for (int k = 0; k < Q; ++k)
 #pragma unroll
       for (int m = 0; m < NMET; ++m) {
-        const bool lt = tm[k][m] < best[k][m];   // strict: earlier sub-tile keeps ties (lowest index wins)
-        best[k][m] = lt ? tm[k][m] : best[k][m];
-        btile[k][m] = lt ? t : btile[k][m];
+        btile[k][m] = (other[k][m] < best[k][m]) ? t : btile[k][m];
+        best[k][m] = other[k][m];
       }
   }
 }
