@@ -6,6 +6,7 @@ sys.path.insert(0, ROOT)
 import numpy as np, torch
 from houv_amd import ops, synthetic
 dev = torch.device("cuda:0")
+torch.manual_seed(0)   # same clouds for every variant: the checksums must agree
 out = []
 CASES = (("uniform", 4096, 2048), ("uniform", 8192, 2048), ("mvp", 4096, 2048), ("uniform", 4096, 1024), ("uniform", 2048, 4096))
 if os.environ.get("ONLY"):
