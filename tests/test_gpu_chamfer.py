@@ -108,17 +108,18 @@ def test_filter_uncertainty_paths_bit_exact(dev, B, N, M, offset, dups):
     assert np.array_equal(d2.cpu().numpy().view(np.uint32), o2.view(np.uint32))
 
 
-def test_filter_and_direct_kernels_agree_on_nonfinite_inputs(dev):
+@pytest.mark.parametrize("N,M", [(300, 500), (1500, 2300)])     # compiled sub-tile loop (Q = 2) / the assembly loop (Q = 8, two LDS passes)
+def test_filter_and_direct_kernels_agree_on_nonfinite_inputs(dev, N, M):
     """NaN / Inf coordinates: such references never win in either kernel (v_min3 drops NaN); a query with no finite
     distance reports reference 0 (chamfer3D.cu:37).  The filtered kernel must behave exactly like the direct sweep it
     replaces -- compared through a second process-free route: the same inputs with the bad points removed."""
     gen = torch.Generator().manual_seed(11)
-    a = torch.rand(2, 300, 3, generator=gen)
-    b = torch.rand(2, 500, 3, generator=gen)
+    a = torch.rand(2, N, 3, generator=gen)
+    b = torch.rand(2, M, 3, generator=gen)
     bad = b.clone()
-    bad[:, 7] = float("nan"); bad[:, 130, 1] = float("inf"); bad[:, 499] = float("-inf")
+    bad[:, 7] = float("nan"); bad[:, 130, 1] = float("inf"); bad[:, M - 1] = float("-inf")
     d1, _, i1, _ = _cd(a, bad, dev)
-    keep = torch.tensor([j for j in range(500) if j not in (7, 130, 499)])
+    keep = torch.tensor([j for j in range(M) if j not in (7, 130, M - 1)])
     e1, _, k1, _ = _cd(a, b[:, keep].contiguous(), dev)
     assert torch.equal(d1, e1) and torch.equal(keep.to(dev)[k1.long()], i1.long())
     allbad = torch.full((1, 40, 3), float("nan"))
