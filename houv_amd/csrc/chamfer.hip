@@ -406,20 +406,23 @@ __global__ __launch_bounds__(kBlock, 4) void chamfer_nn_filter_kernel(const floa
       idx[qi] = j2;
     }
   }
-  // Phase B.2: exact scan of every reference, eight lanes per entry (lane s takes references s, s+8, ... in ascending
-  // order with strict <, then the eight partial results are merged: smaller distance, lower index on ties)
+  // Phase B.2: exact scan of every reference, `lpe` lanes per entry -- a whole wave when the list holds at most four
+  // queries (the usual case: ~0.1 % of the queries), eight when it is long.  Lane s of an entry takes references s, s+lpe, ...
+  // in ascending order with strict <, then the partial results are merged: smaller distance, lower index on ties.
   const int n3 = min(s_n3, kList3);
+  const int lsh = n3 <= 4 ? 6 : (n3 <= 8 ? 5 : (n3 <= 16 ? 4 : 3)), lpe = 1 << lsh;
 #pragma unroll 1
-  for (int base = 0; base < n3; base += kBlock / 8) {
-    const int i = base + (tid >> 3), sub = tid & 7;
+  for (int base = 0; base < n3; base += kBlock >> lsh) {
+    const int i = base + (tid >> lsh), sub = tid & (lpe - 1);
     const bool act = i < n3;
+    if (!__any(act)) continue;                       // waves without an entry in this pass
     const int qi = q0 + (act ? (int)s_list3[i] : 0);
     const float qx = act ? q[qi * 3 + 0] : 0.f, qy = act ? q[qi * 3 + 1] : 0.f, qz = act ? q[qi * 3 + 2] : 0.f;
     float d3 = INFINITY;
     int j3 = 0x7fffffff;
     if (resident) {
 #pragma unroll 4
-      for (int j = sub; j < nr; j += 8) {
+      for (int j = sub; j < nr; j += lpe) {
         const float4 p = s_ref[j];
         const float d = metric_sqdist<0>(p.x - qx, p.y - qy, p.z - qz);
         const bool lt = d < d3;
@@ -428,15 +431,14 @@ __global__ __launch_bounds__(kBlock, 4) void chamfer_nn_filter_kernel(const floa
       }
     } else {
 #pragma unroll 4
-      for (int j = sub; j < nr; j += 8) {
+      for (int j = sub; j < nr; j += lpe) {
         const float d = metric_sqdist<0>(r[j * 3 + 0] - qx, r[j * 3 + 1] - qy, r[j * 3 + 2] - qz);
         const bool lt = d < d3;
         d3 = lt ? d : d3;
         j3 = lt ? j : j3;
       }
     }
-#pragma unroll
-    for (int o = 1; o < 8; o <<= 1) {
+    for (int o = 1; o < lpe; o <<= 1) {
       const float dq = __shfl_xor(d3, o, kWave);
       const int jo = __shfl_xor(j3, o, kWave);
       const bool take = dq < d3 || (dq == d3 && jo < j3);
