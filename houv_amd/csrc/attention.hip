@@ -41,6 +41,9 @@ struct AttnArgs {
   float scale;
 };
 
+// FULL: Nq % 128 == 0 and Nk % 32 == 0 (the launcher checks): no row / key guards -- no exec-mask branches around the loads, no
+// masking compares in the softmax.
+template <bool FULL>
 __global__ __launch_bounds__(256, 2) void attention_f32_kernel(AttnArgs g) {
   __shared__ float Ks[kDk * kLdK + 32];
   __shared__ __attribute__((aligned(16))) float Vs[kBk * kLdV];
@@ -56,10 +59,10 @@ __global__ __launch_bounds__(256, 2) void attention_f32_kernel(AttnArgs g) {
   // this lane's query row, dims half*64 .. +63 (zeros for rows beyond Nq: computed, never stored)
   float qf[64];
   {
-    const float* qp = Q + (size_t)(q < g.Nq ? q : 0) * g.ldq + half * 64;
+    const float* qp = Q + (size_t)(FULL || q < g.Nq ? q : 0) * g.ldq + half * 64;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-      const float4 v = (q < g.Nq) ? *reinterpret_cast<const float4*>(qp + 4 * i) : make_float4(0.f, 0.f, 0.f, 0.f);
+      const float4 v = (FULL || q < g.Nq) ? *reinterpret_cast<const float4*>(qp + 4 * i) : make_float4(0.f, 0.f, 0.f, 0.f);
       qf[4 * i + 0] = v.x; qf[4 * i + 1] = v.y; qf[4 * i + 2] = v.z; qf[4 * i + 3] = v.w;
     }
   }
@@ -76,7 +79,7 @@ __global__ __launch_bounds__(256, 2) void attention_f32_kernel(AttnArgs g) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int key = k0 + (tid >> 5) + 8 * i, d = (tid & 31) * 4;
-      const bool ok = key < g.Nk;
+      const bool ok = FULL || key < g.Nk;
       rk[i] = ok ? *reinterpret_cast<const float4*>(K + (size_t)key * g.ldk + d) : make_float4(0.f, 0.f, 0.f, 0.f);
       rv[i] = ok ? *reinterpret_cast<const float4*>(V + (size_t)key * g.ldv + d) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
@@ -111,7 +114,7 @@ __global__ __launch_bounds__(256, 2) void attention_f32_kernel(AttnArgs g) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-      s[r] = (key < g.Nk) ? s[r] * g.scale : -INFINITY;
+      s[r] = (FULL || key < g.Nk) ? s[r] * g.scale : -INFINITY;
       mx = fmaxf(mx, s[r]);
     }
     mx = fmaxf(mx, __shfl_xor(mx, 32, kWave));
@@ -141,7 +144,7 @@ __global__ __launch_bounds__(256, 2) void attention_f32_kernel(AttnArgs g) {
   }
 
   // ---- O[q][dims] = O^T / l: a lane holds, per dim tile t and group gq = r >> 2, dims t*32 + 8 gq + 4 half .. +3 ----
-  if (q < g.Nq) {
+  if (FULL || q < g.Nq) {
     const float inv = 1.0f / l_run;
     float* op = O + (size_t)q * g.ldo;
 #pragma unroll
@@ -175,6 +178,7 @@ extern "C" int houv_attention_f32(const float* Q, const float* K, const float* V
   }
   AttnArgs g{Q, K, V, O, Nq, Nk, ldq, ldk, ldv, ldo, sQ, sK, sV, sO, scale};
   dim3 grid((Nq + kBq - 1) / kBq, H, P);
-  attention_f32_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(g);
+  if (Nq % kBq == 0 && Nk % kBk == 0) attention_f32_kernel<true><<<grid, 256, 0, (hipStream_t)stream>>>(g);
+  else attention_f32_kernel<false><<<grid, 256, 0, (hipStream_t)stream>>>(g);
   return check_launch("houv_attention_f32") ? 1 : 0;
 }
