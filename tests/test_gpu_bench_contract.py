@@ -45,3 +45,43 @@ def test_bench_line_contract(monkeypatch):
     assert r["launches"] > 0 and r["kernel_time_share"] <= 1.0 and "traffic" in r
     p = d["pruned"]
     assert p["bit_identical_to_brute_force"] is True and p["unit"] == "pairs/s" and p["steps"] >= 5
+
+
+def _launch(cmd, cwd, env, q):
+    import subprocess
+    res = subprocess.run(cmd, cwd=cwd, env=env, capture_output=True, text=True, timeout=600)
+    q.put((res.returncode, res.stdout, res.stderr[-3000:]))
+
+
+def test_bench_two_ranks_as_the_driver_launches_it():
+    """The N > 1 launch line of the driver (python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...), rehearsed
+    with two ranks on the ONE GPU of the test box: --backend gloo --single-device swap RCCL for gloo and put both ranks on
+    cuda:0; everything else (rank-local batches, one all-gather of every step's transforms, barrier + max-over-ranks
+    timing, rank 0 printing the single JSON line) is the code path of the 8-GPU run.  The launcher is started from the
+    forkserver (conftest.py: a process that never touched the GPU), not forked from this one."""
+    import multiprocessing as mp
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--single-device",
+           "--steps", "2", "--warmup", "1", "--pairs", "8", "--points", "512", "--kernel", "26", "--iters", "40"]
+    ctx = mp.get_context("forkserver")
+    q = ctx.Queue()
+    proc = ctx.Process(target=_launch, args=(cmd, ROOT, env, q))
+    proc.start()
+    rc, out, err = q.get(timeout=700)
+    proc.join(timeout=60)
+    assert rc == 0, err
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out[-2000:]                             # rank 0 only
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["steps"] == 2
+    assert abs(d["value"] - 2 * 8 * 2 / (d["ms_per_step"] * 2e-3)) < 1e-6 * d["value"]      # whole-job pairs/s: both ranks' pairs
+    assert "dp2" in d["config"]["parallelism"] and d["config"]["pairs_per_gpu"] == 8
+    assert "pruned" not in d and "cpu_baseline" not in d and "chamfer_op" not in d          # N = 1 extras stay off
+    assert d["quality"]["hypothesis_iterations_per_pair"] >= 26 * 40
