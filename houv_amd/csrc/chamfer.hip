@@ -138,6 +138,10 @@ constexpr float kUlpHalf = 5.9604645e-8f;   // u = 2^-24
 constexpr int kList2 = 1024, kList3 = 256;   // capacities of the per-workgroup recovery work lists (LDS)
 
 // exact (direct-difference) minimum of one 32-reference sub-tile and the lowest index attaining it
+__device__ __forceinline__ float filter_e(float ex, float ey, float ez, float px, float py, float pz, float pw) {
+  return __builtin_fmaf(ex, px, __builtin_fmaf(ey, py, __builtin_fmaf(ez, pz, pw)));
+}
+
 template <bool FROM_LDS>
 __device__ __forceinline__ void exact_tile(const float4* __restrict__ s_ref, const float* __restrict__ r, int tile, int nr,
                                            float qx, float qy, float qz, int rot, float& bd, int& jb) {
@@ -350,7 +354,7 @@ __global__ __launch_bounds__(kBlock, 4) void chamfer_nn_filter_kernel(const floa
   const float rmax = sqrtf(__uint_as_float(s_rmax));   // visible: written before the last tile's barrier
   const bool resident = nr <= kRefTile;                // single LDS pass: every sub-tile is still in s_ref
   const int rot = tid & (kSub - 1);
-  unsigned ovf2 = 0u, ovf3 = 0u;
+  unsigned ovf2 = 0u, ovf3 = 0u, ovfa = 0u;   // list overflows; ovfa: the owed sub-tile is the best one, not the second
 #pragma unroll 1
   for (int k = 0; k < Q; ++k) {
     const int ql = k * kBlock + tid, qi = q0 + ql;
@@ -363,8 +367,31 @@ __global__ __launch_bounds__(kBlock, 4) void chamfer_nn_filter_kernel(const floa
     const bool need2 = valid && finite && !need3 && !(sec[k] > best[k] + tau);
     float bd = INFINITY;
     int jb = 0x7fffffff;
-    if (resident) exact_tile<true>(s_ref, r, bt[k], nr, qx, qy, qz, rot, bd, jb);
-    else exact_tile<false>(s_ref, r, bt[k], nr, qx, qy, qz, rot, bd, jb);
+    // The exact arg-min of the best sub-tile is one of its references with e <= min e + tau (the bound above, applied to the
+    // sub-tile; every reference tying with it in d is one too).  Counting them costs 3 FMAs + 3 half-rate instructions per
+    // reference against ~12 for the exact scan with its index tie-break; nearly always there is exactly one, whose exact
+    // distance is then the answer.  Any other count (ties, lattices, non-finite thresholds) still owes the exact scan of the
+    // sub-tile: the query joins the "one more sub-tile" work list of phase B.1 with its BEST sub-tile.
+    int cand = 0, jc = 0;
+    bool amb = false;                      // ambiguous: the exact scan of the best sub-tile is still owed (work list below)
+    if (resident) {
+      const float thr = best[k] + tau;
+      const int base = bt[k] * kSub;
+#pragma unroll 8
+      for (int jr = 0; jr < kSub; ++jr) {
+        const int jj = base + ((jr + rot) & (kSub - 1));   // rotated: lanes sit on different bank quads whatever their tile
+        const float4 p = s_ref[jj];
+        const bool c = filter_e(ex[k], ey[k], ez[k], p.x, p.y, p.z, p.w) <= thr;   // false for NaN e, for padding (e = +inf)
+        jc = c ? jj : jc;
+        cand += c ? 1 : 0;
+      }
+      const float4 p = s_ref[jc];          // jc = 0 without a candidate: still a reference, its exact distance a valid provisional
+      bd = metric_sqdist<0>(p.x - qx, p.y - qy, p.z - qz);
+      jb = jc;
+      amb = valid && finite && cand != 1;
+    } else {
+      exact_tile<false>(s_ref, r, bt[k], nr, qx, qy, qz, rot, bd, jb);
+    }
     if (!finite) {
       // no finite distance at all (NaN / overflowing input): the reference reports ref 0 (chamfer3D.cu:37)
       bd = metric_sqdist<0>(r[0] - qx, r[1] - qy, r[2] - qz);
@@ -374,19 +401,19 @@ __global__ __launch_bounds__(kBlock, 4) void chamfer_nn_filter_kernel(const floa
       dist[qi] = bd;
       idx[qi] = jb;
     }
-    if (need3) {
+    if (need3 || (need2 && amb)) {         // two sub-tiles owed to one query would race on its result: take the full scan
       const int slot = atomicAdd(&s_n3, 1);
       if (slot < kList3) s_list3[slot] = (unsigned short)ql;
       else ovf3 |= 1u << k;
-    } else if (need2) {
+    } else if (need2 || amb) {
       const int slot = atomicAdd(&s_n2, 1);
-      if (slot < kList2) s_list2[slot] = (unsigned)ql | ((unsigned)bt2[k] << 11);
-      else ovf2 |= 1u << k;
+      if (slot < kList2) s_list2[slot] = (unsigned)ql | ((unsigned)(need2 ? bt2[k] : bt[k]) << 11);
+      else { ovf2 |= 1u << k; ovfa |= amb ? 1u << k : 0u; }
     }
   }
   __syncthreads();   // lists complete; the provisional results are visible to the whole workgroup
 
-  // Phase B.1: second sub-tile, one lane per entry
+  // Phase B.1: one more sub-tile (the second one, or the best one of an ambiguous query), one lane per entry
   const int n2 = min(s_n2, kList2);
 #pragma unroll 1
   for (int base = 0; base < n2; base += kBlock) {
@@ -463,8 +490,9 @@ __global__ __launch_bounds__(kBlock, 4) void chamfer_nn_filter_kernel(const floa
       if (__any(o2)) {
         float d2 = INFINITY;
         int j2 = 0x7fffffff;
-        if (resident) exact_tile<true>(s_ref, r, bt2[k], nr, qx, qy, qz, rot, d2, j2);
-        else exact_tile<false>(s_ref, r, bt2[k], nr, qx, qy, qz, rot, d2, j2);
+        const int t2 = ((ovfa >> k) & 1u) ? bt[k] : bt2[k];
+        if (resident) exact_tile<true>(s_ref, r, t2, nr, qx, qy, qz, rot, d2, j2);
+        else exact_tile<false>(s_ref, r, t2, nr, qx, qy, qz, rot, d2, j2);
         const bool take = o2 && (d2 < bd || (d2 == bd && j2 < jb));
         bd = take ? d2 : bd;
         jb = take ? j2 : jb;
