@@ -4,6 +4,7 @@
     python tests/golden/make_golden_r2.py traj2048       # G15: trajectory at 2048 points (BASELINE configs[1]'s cloud size)
     python tests/golden/make_golden_r2.py envelope 128   # G16: chaos envelope of predict_model, G12's first 16 pairs
     python tests/golden/make_golden_r2.py envelope 512   # G17: same on G13's first 6 pairs (configs[0]'s cloud size)
+    python tests/golden/make_golden_r2.py envelope 2048  # G20: same on G15's 2048x2048-point pair (the bench's cloud size; ~1.5 h of CPU)
     python tests/golden/make_golden_r2.py twin           # G18: chaos envelope of train_utils.getPredict_angle (lr 0.1)
 
 The reference is imported exactly as make_golden.py does (its own chamfer_python.py stands in for the CUDA extension).
@@ -129,8 +130,10 @@ def main():
         K, hs = 26, (20, 50, 100, 200)
         if N == 128:
             g = np.load(os.path.join(HERE, "g12_stat.npz")); P, name = 16, "g16_envelope128.npz"
-        else:
+        elif N == 512:
             g = np.load(os.path.join(HERE, "g13_stat512.npz")); P, name = 6, "g17_envelope512.npz"
+        else:
+            g = np.load(os.path.join(HERE, "g15_traj2048.npz")); P, name = 1, "g20_envelope2048.npz"   # BASELINE configs[1]'s cloud size
         src, tgt = torch.tensor(g["src"][:P]), torch.tensor(g["tgt"][:P])
         out = dict(src=src.numpy(), tgt=tgt.numpy(), kernel=np.int64(K), horizons=np.array(hs))
         # two independent relative 1e-7 perturbations of the inputs: the envelope is the larger of the two divergences
