@@ -346,10 +346,10 @@ __global__ __launch_bounds__(kBlock, 4) void chamfer_nn_filter_kernel(const floa
   }
 
   // ---- exact recovery ------------------------------------------------------------------------------------------
-  // Phase A (dense, every lane): exact minimum of the best sub-tile -> provisional (dist, idx) in global memory.  Queries
-  // whose second / third sub-tile lies within tau are NOT finished in place -- a wave would run the extra work for
-  // all 64 lanes whenever one lane asks for it -- but appended to two LDS work lists.
-  // Phase B (after a barrier): the lists are worked off densely: one lane per "second sub-tile" entry, eight lanes per
+  // Phase A (dense, every lane): the best sub-tile -> provisional (dist, idx) in global memory.  Queries that owe more work
+  // -- an ambiguous best sub-tile, a second / third sub-tile within tau -- are NOT finished in place (a wave would run the
+  // extra work for all 64 lanes whenever one lane asks for it) but appended to two LDS work lists.
+  // Phase B (after a barrier): the lists are worked off densely: one lane per "one more sub-tile" entry, 8 to 64 lanes per
   // "exact full scan" entry.  Lists that overflow (pathological inputs: everything tied) spill to the in-lane path.
   const float rmax = sqrtf(__uint_as_float(s_rmax));   // visible: written before the last tile's barrier
   const bool resident = nr <= kRefTile;                // single LDS pass: every sub-tile is still in s_ref
