@@ -76,10 +76,11 @@ def _inside_envelope(gpu, env, floor, what):
             assert (gpu > thr).sum() <= 3 * (env > thr).sum() + 3, (what, thr, int((gpu > thr).sum()), int((env > thr).sum()))
 
 
-@pytest.mark.parametrize("fixture", ["g16_envelope128.npz", "g17_envelope512.npz"])
+@pytest.mark.parametrize("fixture", ["g16_envelope128.npz", "g17_envelope512.npz", "g20_envelope2048.npz"])
 def test_predict_model_stays_inside_the_references_chaos_envelope(golden, dev, fixture):
-    """G16 (16 pairs x 128 points) / G17 (6 pairs x 512 points, BASELINE configs[0]'s cloud size), K=26, base 0:
-    predict_model (houv.py:106-138) at 20/50/100/200 iterations, per hypothesis, against the reference and its envelope."""
+    """G16 (16 pairs x 128 points) / G17 (6 pairs x 512 points, BASELINE configs[0]'s cloud size) / G20 (G15's 2048 x 2048-point
+    pair: BASELINE configs[1]'s cloud size, the kernel instantiation bench.py times), K=26, base 0: predict_model
+    (houv.py:106-138) at 20/50/100/200 iterations, per hypothesis, against the reference and its envelope."""
     from houv_amd.models.houv import HOUV, predict_model
     g = golden(fixture)
     K = int(g["kernel"])
