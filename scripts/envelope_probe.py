@@ -12,7 +12,7 @@ def q(x):
     return "q50 %.2e q90 %.2e q99 %.2e max %.2e  frac>1e-3 %.3f" % (np.median(x), np.quantile(x, .9), np.quantile(x, .99), x.max(), (x > 1e-3).mean())
 
 
-for name in ("g16_envelope128.npz", "g17_envelope512.npz", "g20_envelope2048.npz", "g18_twin_envelope.npz"):
+for name in ("g16_envelope128.npz", "g17_envelope512.npz", "g20_envelope2048.npz", "g18_twin_envelope.npz", "g21_twin_envelope2048.npz"):
     path = os.path.join(ROOT, "tests", "golden", name)
     if not os.path.exists(path):
         continue

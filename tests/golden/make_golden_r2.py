@@ -6,6 +6,7 @@
     python tests/golden/make_golden_r2.py envelope 512   # G17: same on G13's first 6 pairs (configs[0]'s cloud size)
     python tests/golden/make_golden_r2.py envelope 2048  # G20: same on G15's 2048x2048-point pair (the bench's cloud size; ~1.5 h of CPU)
     python tests/golden/make_golden_r2.py twin           # G18: chaos envelope of train_utils.getPredict_angle (lr 0.1)
+    python tests/golden/make_golden_r2.py twin 2048      # G21: the same on G15's 2048x2048-point pair
 
 The reference is imported exactly as make_golden.py does (its own chamfer_python.py stands in for the CUDA extension).
 Nothing of it is edited: per-iteration snapshots are taken from OUTSIDE, by wrapping the module-level functions its
@@ -145,8 +146,9 @@ def main():
         np.savez_compressed(os.path.join(HERE, name), **out)
     elif what == "twin":
         K, hs = 26, (5, 20, 50, 100)
-        g = np.load(os.path.join(HERE, "g12_stat.npz"))
-        P = 8
+        big = len(sys.argv) > 2 and sys.argv[2] == "2048"      # `twin 2048`: G21, G15's 2048x2048-point pair
+        g = np.load(os.path.join(HERE, "g15_traj2048.npz" if big else "g12_stat.npz"))
+        P = 1 if big else 8
         src, tgt = torch.tensor(g["src"][:P]), torch.tensor(g["tgt"][:P])
         out = dict(src=src.numpy(), tgt=tgt.numpy(), kernel=np.int64(K), horizons=np.array(hs), np_seed=np.int64(31))
         for tag, fs, ft in (("ref", 1.0, 1.0), ("pertA", 1.0 + 1e-7, 1.0), ("pertB", 1.0, 1.0 - 1e-7)):
@@ -154,7 +156,7 @@ def main():
             pack(out, tag, snaps)
             out[f"{tag}_tran_s"] = ts
             print("twin", tag, "done", flush=True)
-        np.savez_compressed(os.path.join(HERE, "g18_twin_envelope.npz"), **out)
+        np.savez_compressed(os.path.join(HERE, "g21_twin_envelope2048.npz" if big else "g18_twin_envelope.npz"), **out)
     else:
         raise SystemExit("unknown target " + what)
 

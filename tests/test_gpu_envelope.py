@@ -93,13 +93,15 @@ def test_predict_model_stays_inside_the_references_chaos_envelope(golden, dev, f
             _inside_envelope(_divergence(val.cpu().numpy(), ref), env, floor, (fixture, h, key))
 
 
-def test_solve_twin_stays_inside_the_references_chaos_envelope(golden, dev):
-    """G18: train_utils.getPredict_angle (train_utils.py:359-456: float64 leaves from the harness-seeded global numpy RNG,
+@pytest.mark.parametrize("fixture", ["g18_twin_envelope.npz", "g21_twin_envelope2048.npz"])
+def test_solve_twin_stays_inside_the_references_chaos_envelope(golden, dev, fixture):
+    """G21: the same on G15's 2048 x 2048-point pair (the single-metric kernel instantiation at BASELINE configs[1]'s size).
+    G18: train_utils.getPredict_angle (train_utils.py:359-456: float64 leaves from the harness-seeded global numpy RNG,
     lr 0.1, sigma = sin(s pi), loss 6 min_1) on 8 pairs x 128 points, K=26, base 1, at 5/20/50/100 iterations.  At lr 0.1
     a fifth of the hypotheses has left the 1e-3 ball after 20 iterations in the reference's own perturbed runs; the
     kernel's divergence has the same distribution.  Also the 4th return value: tran_s of the LAST forward (:404,456)."""
     from houv_amd.train_utils import getPredict_angle
-    g = golden("g18_twin_envelope.npz")
+    g = golden(fixture)
     K = int(g["kernel"])
     s, t = T(g["src"]).to(dev), T(g["tgt"]).to(dev)
     for h in (int(x) for x in g["horizons"]):
@@ -108,9 +110,9 @@ def test_solve_twin_stays_inside_the_references_chaos_envelope(golden, dev):
         for key, val, floor in (("R", R, 2.4e-7), ("T", Tt, 2.4e-7), ("min1", m1, 1.5e-8)):
             ref = g[f"ref_n{h}_{key}"]
             env = np.maximum(_divergence(g[f"pertA_n{h}_{key}"], ref), _divergence(g[f"pertB_n{h}_{key}"], ref))
-            _inside_envelope(_divergence(val.cpu().numpy(), ref), env, floor, ("g18", h, key))
+            _inside_envelope(_divergence(val.cpu().numpy(), ref), env, floor, (fixture, h, key))
     # tran_s belongs to the last forward, like the R / T / min_1 it is returned with: |T| == |sigma|
     ref_ts = g["ref_tran_s"]
     env = np.maximum(np.abs(g["pertA_tran_s"] - ref_ts), np.abs(g["pertB_tran_s"] - ref_ts)).reshape(-1)
-    _inside_envelope(np.abs(ts.cpu().numpy() - ref_ts).reshape(-1), env, 2.4e-7, ("g18", "tran_s"))
+    _inside_envelope(np.abs(ts.cpu().numpy() - ref_ts).reshape(-1), env, 2.4e-7, (fixture, "tran_s"))
     np.testing.assert_allclose(np.abs(ts.cpu().numpy().reshape(-1)), Tt.reshape(-1, 3).norm(dim=1).cpu().numpy(), atol=1e-5)
