@@ -21,6 +21,8 @@ _flt = ctypes.c_float
 _SIGNATURES = {
     "houv_abi_version": (ctypes.c_int, []),
     "houv_last_error": (ctypes.c_char_p, []),
+    "houv_build_id": (ctypes.c_char_p, []),
+    "houv_debug_set": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_longlong]),
     "houv_chamfer_forward": (ctypes.c_int, [_c_f, _c_f, _int, _int, _int, _c_f, _c_f, _c_f, _c_f, _c_f]),
     "houv_chamfer_backward": (ctypes.c_int, [_c_f, _c_f, _int, _int, _int, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f]),
     "houv_kabsch": (ctypes.c_int, [_c_f, _c_f, _c_f, _int, _int, _c_f, _c_f, _c_f]),
@@ -85,6 +87,16 @@ def solve_variant(N, M, pruned=False):
     b, q = ctypes.c_int(0), ctypes.c_int(0)
     check(load().houv_solve_variant(int(N), int(M), int(bool(pruned)), ctypes.byref(b), ctypes.byref(q)), "houv_solve_variant")
     return b.value, q.value
+
+
+def build_id():
+    """Hash of the sources the loaded library was built from (houv_build_id)."""
+    return load().houv_build_id().decode()
+
+
+def debug_set(name, value):
+    """Diagnostic switch of the library (houv_debug_set; see houv_amd/csrc/houv_common.h `DebugKnobs`)."""
+    check(load().houv_debug_set(name.encode(), int(value)), "houv_debug_set")
 
 
 def last_error():

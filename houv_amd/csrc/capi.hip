@@ -18,6 +18,8 @@ void set_error(const char* fmt, ...) {
   fprintf(stderr, "[houv_hip] %s\n", g_err);
 }
 
+DebugKnobs g_debug;
+
 namespace {
 
 // HOUV.forward (registration/models/houv.py:94-103): one thread per hypothesis builds R,T; the
@@ -56,6 +58,30 @@ __global__ void move_kernel(const float* __restrict__ src, const float* __restri
 extern "C" int houv_abi_version(void) { return HOUV_ABI_VERSION; }
 
 extern "C" const char* houv_last_error(void) { return houv::g_err; }
+
+extern "C" int houv_debug_set(const char* name, long long value) {
+  using namespace houv;
+  const struct { const char* name; std::atomic<int>* knob; long long lo, hi; } ints[] = {
+      {"solve_predict", &g_debug.pred_mode, 0, 2},   {"prune_refresh", &g_debug.ws_refresh, 0, 1 << 30},
+      {"chamfer_direct", &g_debug.chamfer_direct, 0, 1}, {"chamfer_q", &g_debug.chamfer_q, 1, 8},
+      {"gemm_4w", &g_debug.gemm_4w, 0, 1},           {"gemm_guarded", &g_debug.gemm_guarded, 0, 1}};
+  if (name && !strcmp(name, "solve_stats")) {
+    g_debug.stats = (unsigned long long)value;
+    return 1;
+  }
+  for (const auto& k : ints)
+    if (name && !strcmp(name, k.name) && value >= k.lo && value <= k.hi) {
+      *k.knob = (int)value;
+      return 1;
+    }
+  set_error("houv_debug_set: unknown switch or value out of range: %s = %lld", name ? name : "(null)", value);
+  return 0;
+}
+
+#ifndef HOUV_BUILD_ID
+#define HOUV_BUILD_ID "unknown"
+#endif
+extern "C" const char* houv_build_id(void) { return HOUV_BUILD_ID; }
 
 extern "C" int houv_pose_forward(const float* params, int n, int angle_base, int trans_mode, const float* src, int N,
                                  float* R, float* T, float* moved, void* stream) {

@@ -363,7 +363,11 @@ __global__ __launch_bounds__(kBlock, 4) void chamfer_nn_filter_kernel(const floa
     const float qx = -0.5f * ex[k], qy = -0.5f * ey[k], qz = -0.5f * ez[k];
     const float qn = sqrtf(metric_sqdist<0>(qx, qy, qz));
     const float tau = 25.0f * kUlpHalf * (rmax + qn) * (rmax + qn) + 1e-30f;
-    const bool need3 = valid && finite && !(third[k] > best[k] + tau);           // written so that NaN / inf thresholds say "needed"
+    // !finite: the FILTER saw no finite value -- for NaN / Inf inputs, but also for finite coordinates beyond ~1.3e19, where
+    // |r|^2 overflows and e = -inf + inf = NaN for every reference while a direct difference (r - q)^2 may still be finite:
+    // such a query takes the exact full scan (which leaves the provisional reference-0 answer of chamfer3D.cu:37 in place
+    // when no distance is finite).
+    const bool need3 = valid && (!finite || !(third[k] > best[k] + tau));        // written so that NaN / inf thresholds say "needed"
     const bool need2 = valid && finite && !need3 && !(sec[k] > best[k] + tau);
     float bd = INFINITY;
     int jb = 0x7fffffff;
@@ -614,8 +618,8 @@ extern "C" int houv_chamfer_forward(const float* xyz1, const float* xyz2, int B,
   }
   hipStream_t s = (hipStream_t)stream;
   const int mx = N > M ? N : M;
-  static const bool direct = [] { const char* e = getenv("HOUV_CHAMFER_DIRECT"); return e && e[0] == '1'; }();
-  static const int qmax = [] { const char* e = getenv("HOUV_CHAMFER_Q"); return e ? atoi(e) : 8; }();   // diagnostics only
+  const bool direct = g_debug.chamfer_direct.load() != 0;   // houv_debug_set: A/B diagnostics only
+  const int qmax = g_debug.chamfer_q.load();
   int q = mx <= kBlock ? 1 : (mx <= 2 * kBlock ? 2 : (mx <= 4 * kBlock || direct ? 4 : 8));
   if (q > qmax) q = qmax;
   const int nqb = (mx + kBlock * q - 1) / (kBlock * q);

@@ -223,8 +223,8 @@ extern "C" int houv_gemm_f32(const float* A, const float* B, float* C, int M, in
   dim3 grid((N + (narrow ? 64 : 128) - 1) / (narrow ? 64 : 128), (M + BM - 1) / BM, outer * inner);
   // 512-thread workgroups (8 waves, 80 registers, up to 6 waves per SIMD) everywhere: against the 256-thread form
   // (4 waves, 139-172 registers) short-K shapes gain 15-25 % (conv 64->128: 47 -> 56, Q K^T: 73 -> 90 TFLOP/s) and the
-  // long-K ones are unchanged; HOUV_GEMM_4W=1 selects the 256-thread kernels for comparison.
-  static const bool four_waves = getenv("HOUV_GEMM_4W") != nullptr;
+  // long-K ones are unchanged; houv_debug_set("gemm_4w", 1) selects the 256-thread kernels for comparison.
+  const bool four_waves = g_debug.gemm_4w.load() != 0;   // houv_debug_set: A/B diagnostics only
   const bool short_k = K <= 256;
   if (four_waves) {
     if (narrow) {
@@ -242,7 +242,7 @@ extern "C" int houv_gemm_f32(const float* A, const float* B, float* C, int M, in
     const int bn = narrow ? 64 : 128;
     const bool aligned16 = !((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) & 15) &&
                            !((lda | ldb | (int)(sAo & 3) | (int)(sAi & 3) | (int)(sBo & 3) | (int)(sBi & 3)) & 3);
-    static const bool force_guard = getenv("HOUV_GEMM_GUARDED") != nullptr;   // diagnostics / A-B only
+    const bool force_guard = g_debug.gemm_guarded.load() != 0;   // diagnostics / A-B only
     const bool full = !force_guard && aligned16 && M % BM == 0 && N % bn == 0 && K % BK == 0;
     if (narrow) {
       if (trans_b) { if (full) gemm_f32_kernel<64, true, 6, 4, false><<<grid, 512, 0, s>>>(g); else gemm_f32_kernel<64, true, 6, 4><<<grid, 512, 0, s>>>(g); }

@@ -4,6 +4,8 @@
 #include <stdint.h>
 #include <stdio.h>
 
+#include <atomic>
+
 #include "houv_math.h"
 
 namespace houv {
@@ -21,6 +23,25 @@ inline bool check_launch(const char* what) {
   }
   return true;
 }
+
+// Diagnostic switches (houv_debug_set; tests, A/B scripts and bench.py only -- never the environment).  Results are proven
+// independent of every switch except the two that select an alternative kernel for A/B timing (chamfer_direct, gemm_*).
+//   "solve_predict"   0 normal; 1 always predict direction B (every A-win takes the repair path); 2 rescan everything
+//   "prune_refresh"   pruned mode: every n-th iteration refreshes every remembered nearest neighbour (default 2)
+//   "solve_stats"     device address of 4 uint64 counters the fused loop's sweeps add to (0 = off): see SolveArgs::stats
+//   "chamfer_direct"  1: houv_chamfer_forward runs the direct sweep instead of the filtered one (same bits)
+//   "chamfer_q"       queries per lane cap of the filtered Chamfer kernel (8)
+//   "gemm_4w" / "gemm_guarded"   houv_gemm_f32: 4-wave workgroups / always the guarded tile fetch
+struct DebugKnobs {
+  std::atomic<int> pred_mode{0};
+  std::atomic<int> ws_refresh{2};
+  std::atomic<unsigned long long> stats{0ull};
+  std::atomic<int> chamfer_direct{0};
+  std::atomic<int> chamfer_q{8};
+  std::atomic<int> gemm_4w{0};
+  std::atomic<int> gemm_guarded{0};
+};
+extern DebugKnobs g_debug;
 
 // ---- device side -------------------------------------------------------------------------------
 // The four squared distances share dx,dy,dz.  MET 0: full 3-D; MET 1/2/3: coordinate x/y/z dropped

@@ -217,7 +217,8 @@ template <int BLOCK, int Q, int NMET, int OWN>
 __device__ __forceinline__ void pruned_sweep(const float4* __restrict__ refs, const float4* __restrict__ boxes, int ntile,
                                              const float (&qx)[Q], const float (&qy)[Q], const float (&qz)[Q],
                                              const short* __restrict__ prev, int prev_stride, int count, int rot,
-                                             float (&best)[Q][NMET], int (&btile)[Q][NMET]) {
+                                             float (&best)[Q][NMET], int (&btile)[Q][NMET],
+                                             unsigned long long* __restrict__ stats = nullptr) {
   // G queries share one sub-tile list and every gathered reference (G = 1 by default, see above); a lane's Q/G lists
   // are walked back to back inside ONE loop (a lane moves on to its next list while others are still on their first)
   constexpr int G = (OWN < HOUV_PRUNE_GROUP) ? OWN : HOUV_PRUNE_GROUP;
@@ -263,6 +264,17 @@ __device__ __forceinline__ void pruned_sweep(const float4* __restrict__ refs, co
   for (int k = 0; k < Q; ++k)
 #pragma unroll
     for (int m = 0; m < NMET; ++m) { best[k][m] = INFINITY; btile[k][m] = 0; }
+  int nsteps = 0;   // wave-uniform
+  if (stats) {      // selectivity counters for bench.py's executed-work accounting (houv_debug_set("solve_stats", ptr)); wave-uniform branch
+    int asked = 0;
+#pragma unroll
+    for (int g = 0; g < L; ++g) asked += __popcll(un[g]);
+    asked = wave_incl_scan_dpp(asked);
+    if ((threadIdx.x & 63) == 63) {
+      atomicAdd(&stats[0], (unsigned long long)asked);
+      atomicAdd(&stats[2], 1ull);
+    }
+  }
 #ifdef HOUV_STAMPS
   {
     int asked = 0;
@@ -270,9 +282,22 @@ __device__ __forceinline__ void pruned_sweep(const float4* __restrict__ refs, co
     for (int g = 0; g < L; ++g) asked += __popcll(un[g]);
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) asked += __shfl_xor(asked, o, 64);
+    // union over the wave's 64 lanes of list g (64 consecutive points when OWN == 1), and over all of the wave's lists
+    int uni_g = 0;
+    unsigned long long all = 0ull;
+#pragma unroll
+    for (int g = 0; g < L; ++g) {
+      unsigned long long u = un[g];
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) u |= ((unsigned long long)__shfl_xor((int)(u >> 32), o, 64) << 32) | (unsigned)__shfl_xor((int)u, o, 64);
+      uni_g += __popcll(u);
+      all |= u;
+    }
     if ((threadIdx.x & 63) == 0) {
       atomicAdd(&g_prune_stat[0], (unsigned long long)asked);           // sub-tile visits the wave's lanes asked for
       atomicAdd(&g_prune_stat[2], 1ull);                                // waves
+      atomicAdd(&g_prune_stat[6], (unsigned long long)uni_g);           // sum over lists of the per-list wave unions
+      atomicAdd(&g_prune_stat[7], (unsigned long long)__popcll(all));   // union over the whole wave
     }
   }
   HOUV_PSTAMP(4);
@@ -289,6 +314,7 @@ __device__ __forceinline__ void pruned_sweep(const float4* __restrict__ refs, co
       cur = has ? g : cur;
     }
     if (!__any(mm != 0ull)) break;
+    ++nsteps;
 #ifdef HOUV_STAMPS
     ++steps_;   // sub-tile steps the wave executed
 #endif
@@ -375,6 +401,7 @@ __device__ __forceinline__ void pruned_sweep(const float4* __restrict__ refs, co
           btile[g * G + k][m] = lt ? t : btile[g * G + k][m];
         }
   }
+  if (stats && (threadIdx.x & 63) == 0) atomicAdd(&stats[1], (unsigned long long)nsteps);
 #ifdef HOUV_STAMPS
   if ((threadIdx.x & 63) == 0) atomicAdd(&g_prune_stat[1], steps_);
   HOUV_PSTAMP(5);

@@ -49,6 +49,10 @@ struct SolveArgs {
   int pred_mode;     // diagnostics (HOUV_SOLVE_PREDICT): 0 normal; 1 always predict direction B (every A-win takes the
                      // repair path); 2 rescan everything (no skipping: the round-1 epilogue's work)
   int ws_refresh;    // pruned mode: every ws_refresh-th iteration rescans everything (refreshes every remembered NN)
+  unsigned long long* stats;   // houv_debug_set("solve_stats", device pointer): [0] sub-tile visits the lanes of the pruned sweeps
+                               // asked for, [1] sub-tile steps their waves executed, [2] pruned wave-sweeps, [3] brute wave-sweeps,
+                               // [4] shader clocks (s_memtime) and [5] 100-MHz ticks (s_memrealtime) summed over the workgroups'
+                               // loops: [4]/[5] x 100 MHz = the clock the chip sustained under THIS kernel's load
 };
 
 #ifdef HOUV_STAMPS
@@ -472,6 +476,11 @@ __global__ __launch_bounds__(BLOCK, 4) void solve_kernel(SolveArgs a) {
 #ifdef HOUV_STAMPS
   unsigned long long t_stamp_ = __builtin_readcyclecounter();
 #endif
+  unsigned long long clk0 = 0ull, rt0 = 0ull;   // two stamps per LAUNCH (not per iteration), only when the counters are on
+  if (a.stats) {
+    clk0 = __builtin_amdgcn_s_memtime();
+    rt0 = __builtin_amdgcn_s_memrealtime();
+  }
   constexpr int NW = BLOCK / 64;
   constexpr unsigned kAllMet = (1u << NMET) - 1u;
   // Gradient-direction prediction: bit m = "metric m's min was won by direction A (over the moved points) in the previous
@@ -522,10 +531,11 @@ __global__ __launch_bounds__(BLOCK, 4) void solve_kernel(SolveArgs a) {
       }
       if (pruned_now) {
         if constexpr (PRUNE) {
-          pruned_sweep<BLOCK, Q, NMET, OWN>(sm.tgt, sm.tbox, mpad / kSub, mx, my, mz, ws_a, a.ws_stride, N, rot, best, btile);
+          pruned_sweep<BLOCK, Q, NMET, OWN>(sm.tgt, sm.tbox, mpad / kSub, mx, my, mz, ws_a, a.ws_stride, N, rot, best, btile, a.stats);
         }
       } else {
         sweep<Q, NMET>(sm.tgt, mpad / kSub, mx, my, mz, best, btile);
+        if (a.stats && (tid & 63) == 0) atomicAdd(&a.stats[3], 1ull);
       }
       HOUV_STAMP(1);
       // ---- epilogue A: selection, S of every metric, G/GP of the predicted-A metrics; one barrier ----
@@ -553,10 +563,11 @@ __global__ __launch_bounds__(BLOCK, 4) void solve_kernel(SolveArgs a) {
       const bool pruned_now = PRUNE && ((a.ws_valid != 0) || (it > 0));
       if (pruned_now) {
         if constexpr (PRUNE) {
-          pruned_sweep<BLOCK, Q, NMET, OWN>(sm.mov, sm.mbox, npad / kSub, tx, ty, tz, ws_b, a.ws_stride, M, rot, best, btile);
+          pruned_sweep<BLOCK, Q, NMET, OWN>(sm.mov, sm.mbox, npad / kSub, tx, ty, tz, ws_b, a.ws_stride, M, rot, best, btile, a.stats);
         }
       } else {
         sweep<Q, NMET>(sm.mov, npad / kSub, tx, ty, tz, best, btile);
+        if (a.stats && (tid & 63) == 0) atomicAdd(&a.stats[3], 1ull);
       }
       HOUV_STAMP(3);
       // ---- epilogue B: selection and S first; then the winners are known to every thread ----
@@ -675,6 +686,13 @@ __global__ __launch_bounds__(BLOCK, 4) void solve_kernel(SolveArgs a) {
     HOUV_STAMP(6);
   }
   if (tid < 24) a.state[(size_t)inst * 24 + tid] = sm.state[tid];
+  if (a.stats) {
+    const unsigned long long dc = __builtin_amdgcn_s_memtime() - clk0, dr = __builtin_amdgcn_s_memrealtime() - rt0;
+    if (tid == 0) {
+      atomicAdd(&a.stats[4], dc);
+      atomicAdd(&a.stats[5], dr);
+    }
+  }
 }
 
 template <int BLOCK, int Q, bool PRUNE, int OWN>
@@ -782,15 +800,13 @@ static int solve_dispatch(const float* src, const float* tgt, int P, int N, int 
     set_error("%s: too many hypotheses", who);
     return 0;
   }
+  // pruned mode refreshes every remembered NN on every 2nd iteration (same-device A/B, profiles/r02_ab_pruned_refresh.txt:
+  // 1 -> 0.988, 2 -> 0.960, 4 -> 0.963, 8 -> 0.990, never -> 1.09 us per hypothesis-iteration; results identical in all).
+  // pred_mode / ws_refresh / stats are diagnostics set through houv_debug_set(), never through the environment.
   SolveArgs a{src, tgt, P, N, M, K, state, steps_done, n_iters, angle_base, trans_mode, f64_params, k_full, k_view,
               lr, beta1, beta2, eps, loss_scale, out_score, out_loss, out_R, out_T, out_grad, out_cd, nn_ws, ws_valid,
-              ws_stride, 0, 2};
-  // pruned mode refreshes every remembered NN on every 2nd iteration (same-device A/B, profiles/r02_ab_pruned_refresh.txt:
-  // 1 -> 0.988, 2 -> 0.960, 4 -> 0.963, 8 -> 0.990, never -> 1.09 us per hypothesis-iteration; results identical in all)
-  if (const char* e = getenv("HOUV_PRUNE_REFRESH")) a.ws_refresh = atoi(e);   // diagnostics
-  if (const char* e = getenv("HOUV_SOLVE_PREDICT")) {   // diagnostics: "b" = always predict B (repair path), "all" = rescan everything
-    a.pred_mode = (e[0] == 'b') ? 1 : ((e[0] == 'a') ? 2 : 0);
-  }
+              ws_stride, g_debug.pred_mode.load(), g_debug.ws_refresh.load(),
+              reinterpret_cast<unsigned long long*>(g_debug.stats.load())};
   hipStream_t s = (hipStream_t)stream;
   const int mx = N > M ? N : M;
   int block = 0, q = 0;

@@ -40,8 +40,10 @@ def solve_range(args, l, r, device, kernel, iters, take=None):
 def main(argv=None):
     ap = argparse.ArgumentParser(description='Train config file')
     ap.add_argument('-c', '--config', required=True)
-    ap.add_argument('-l', '--left', default=None, help='solve the left label')
-    ap.add_argument('-r', '--right', default=None, help='solve the right label')
+    # the reference's own defaults, which always override the config's l / r (test_mult.py:87-88,96-97): without -l/-r a
+    # process solves [0, 500) and writes 0_500.npy, exactly what --combine's defaults (step 500, num 4) look for
+    ap.add_argument('-l', '--left', default=0, help='solve the left index')
+    ap.add_argument('-r', '--right', default=500, help='solve the right index')
     ap.add_argument('--combine', default=False, type=str)     # a *string* in the reference: any non-empty value is truthy
     ap.add_argument('--step', type=int, default=500, help='shard size --combine expects (test_mult.py:70: 500)')
     ap.add_argument('--num', type=int, default=4, help='shards --combine expects (test_mult.py:70: 4)')
@@ -49,10 +51,8 @@ def main(argv=None):
     ap.add_argument('--iters', type=int, default=500, help="the reference hard-codes 500 (train_utils.py:488)")
     a = ap.parse_args(argv)
     args = load_config(a.config)
-    if a.left is not None:
-        args.l = int(a.left)
-    if a.right is not None:
-        args.r = int(a.right)
+    args.l = int(a.left)
+    args.r = int(a.right)
     args.combine = a.combine
     # shards and --combine must meet in ONE directory: no time stamp (the reference gets that from load_model's dirname)
     log_dir = _common.make_log_dir(args, stamp=False)

@@ -93,41 +93,60 @@ def pose_forward(params, angle_base, trans_mode=0, src=None):
     return (R, T) if src is None else (R, T, moved)
 
 
+def solve_iterate_out(src, tgt, state, K, steps_done, n_iters, angle_base, trans_mode, use_views, f64_params, k_full,
+                      k_view, lr, beta1, beta2, eps, loss_scale, out_score, out_loss, out_R, out_T, out_grad=None,
+                      out_cd=None, nn_ws=None, ws_valid=0):
+    """The C-ABI call itself, caller-allocated outputs (``houv_solve_iterate`` / ``houv_solve_iterate_pruned`` when a
+    workspace is given): what ``torch.ops.houv.solve_iterate[_pruned]`` bind.  ``state`` [P*K,24] fp64 (and ``nn_ws``) are
+    updated in place; the out_* tensors receive the LAST forward's values.  Returns 1."""
+    _lib.require_gpu(src, tgt, state, out_score, out_loss, out_R, out_T, out_grad, out_cd, nn_ws)
+    _want(src, _F32, "src"); _want(tgt, _F32, "tgt"); _want(state, _F64, "state")
+    P, N, _ = src.shape
+    M = tgt.shape[1]
+    if tgt.shape[0] != P or src.shape[2] != 3 or tgt.shape[2] != 3:
+        raise _lib.HouvHipError("solve_iterate: expected src[P,N,3], tgt[P,M,3]")
+    n = P * int(K)
+    if tuple(state.shape) != (n, 24):
+        raise _lib.HouvHipError(f"solve_iterate: state must be [{n},24], got {tuple(state.shape)}")
+    for t, numel, name in ((out_score, n, "out_score"), (out_loss, n, "out_loss"), (out_R, 9 * n, "out_R"),
+                           (out_T, 3 * n, "out_T"), (out_grad, 8 * n, "out_grad"), (out_cd, 8 * n, "out_cd")):
+        if t is not None:
+            _want(t, _F32, name)
+            if t.numel() != numel:
+                raise _lib.HouvHipError(f"solve_iterate: {name} must hold {numel} floats, got {t.numel()}")
+    common = (_lib.ptr(src), _lib.ptr(tgt), P, N, M, int(K), _lib.ptr(state), int(steps_done), int(n_iters),
+              int(angle_base), int(trans_mode), int(bool(use_views)), int(bool(f64_params)), int(k_full), int(k_view),
+              float(lr), float(beta1), float(beta2), float(eps), float(loss_scale), _lib.ptr(out_score),
+              _lib.ptr(out_loss), _lib.ptr(out_R), _lib.ptr(out_T), _lib.ptr(out_grad), _lib.ptr(out_cd))
+    with torch.cuda.device(src.device):
+        if nn_ws is None:
+            ok = _lib.load().houv_solve_iterate(*common, _lib.stream_of(src))
+        else:   # exact pruned search: nn_ws int16 [P*K, 2, 4, stride] persists between chunked launches
+            if nn_ws.dtype != torch.int16 or tuple(nn_ws.shape[:3]) != (n, 2, 4) or not nn_ws.is_contiguous():
+                raise _lib.HouvHipError("solve_iterate: nn_ws must be a contiguous int16 [P*K,2,4,stride] tensor")
+            ok = _lib.load().houv_solve_iterate_pruned(*common, _lib.ptr(nn_ws), int(ws_valid), nn_ws.shape[3],
+                                                       _lib.stream_of(src))
+    _lib.check(ok, "houv_solve_iterate" + ("_pruned" if nn_ws is not None else ""))
+    return 1
+
+
 def solve_iterate(src, tgt, state, K, *, steps_done, n_iters, angle_base, trans_mode, use_views, f64_params, k_full,
                   k_view, lr, loss_scale, betas=(0.9, 0.999), eps=1e-8, want_grad=False, want_cd=False, nn_ws=None,
                   ws_valid=False):
     """One launch of the fused HOUV loop (houv_solve_iterate).  ``state`` [P*K,24] fp64 is updated in place.
     Returns dict(score[P*K], loss[P*K], R[P*K,3,3], T[P*K,3][, grad[P*K,8]][, cd[P*K,8]]) of the LAST forward."""
     _lib.require_gpu(src, tgt, state)
-    _want(src, _F32, "src"); _want(tgt, _F32, "tgt"); _want(state, _F64, "state")
-    P, N, _ = src.shape
-    M = tgt.shape[1]
-    if tgt.shape[0] != P or src.shape[2] != 3 or tgt.shape[2] != 3:
-        raise _lib.HouvHipError("solve_iterate: expected src[P,N,3], tgt[P,M,3]")
-    if tuple(state.shape) != (P * K, 24):
-        raise _lib.HouvHipError(f"solve_iterate: state must be [{P * K},24], got {tuple(state.shape)}")
     dev = src.device
-    n = P * K
+    n = src.shape[0] * int(K)
     out = dict(score=torch.empty(n, dtype=_F32, device=dev), loss=torch.empty(n, dtype=_F32, device=dev),
                R=torch.empty((n, 3, 3), dtype=_F32, device=dev), T=torch.empty((n, 3), dtype=_F32, device=dev))
     if want_grad:
         out["grad"] = torch.empty((n, 8), dtype=_F32, device=dev)
     if want_cd:
         out["cd"] = torch.empty((n, 8), dtype=_F32, device=dev)
-    common = (_lib.ptr(src), _lib.ptr(tgt), P, N, M, int(K), _lib.ptr(state), int(steps_done), int(n_iters),
-              int(angle_base), int(trans_mode), int(bool(use_views)), int(bool(f64_params)), int(k_full), int(k_view),
-              float(lr), float(betas[0]), float(betas[1]), float(eps), float(loss_scale), _lib.ptr(out["score"]),
-              _lib.ptr(out["loss"]), _lib.ptr(out["R"]), _lib.ptr(out["T"]), _lib.ptr(out.get("grad")),
-              _lib.ptr(out.get("cd")))
-    with torch.cuda.device(dev):
-        if nn_ws is None:
-            ok = _lib.load().houv_solve_iterate(*common, _lib.stream_of(src))
-        else:   # opt-in exact pruned search: nn_ws int16 [P*K, 2, 4, stride] persists between chunked launches
-            if nn_ws.dtype != torch.int16 or tuple(nn_ws.shape[:3]) != (n, 2, 4) or not nn_ws.is_contiguous():
-                raise _lib.HouvHipError("solve_iterate: nn_ws must be a contiguous int16 [P*K,2,4,stride] tensor")
-            ok = _lib.load().houv_solve_iterate_pruned(*common, _lib.ptr(nn_ws), -1 if ws_valid == "verify" else int(bool(ws_valid)), nn_ws.shape[3],
-                                                       _lib.stream_of(src))
-    _lib.check(ok, "houv_solve_iterate" + ("_pruned" if nn_ws is not None else ""))
+    solve_iterate_out(src, tgt, state, K, steps_done, n_iters, angle_base, trans_mode, use_views, f64_params, k_full,
+                      k_view, lr, betas[0], betas[1], eps, loss_scale, out["score"], out["loss"], out["R"], out["T"],
+                      out.get("grad"), out.get("cd"), nn_ws, -1 if ws_valid == "verify" else int(bool(ws_valid)))
     return out
 
 
@@ -175,9 +194,31 @@ def register_torch_ops():
     lib.define("chamfer_backward(Tensor xyz1, Tensor xyz2, Tensor(a!) gradxyz1, Tensor(b!) gradxyz2, Tensor graddist1, "
                "Tensor graddist2, Tensor idx1, Tensor idx2) -> int")
     lib.define("kabsch(Tensor src, Tensor corr, Tensor? weights) -> (Tensor, Tensor)")
+    # the fused loop: the C ABI's argument list, mutable tensors marked; returns 1 like the C call
+    solve_args = ("Tensor src, Tensor tgt, Tensor(a!) state, int K, int steps_done, int n_iters, int angle_base, "
+                  "int trans_mode, bool use_views, bool f64_params, int k_full, int k_view, float lr, float beta1, "
+                  "float beta2, float eps, float loss_scale, Tensor(b!) out_score, Tensor(c!) out_loss, Tensor(d!) out_R, "
+                  "Tensor(e!) out_T, Tensor(f!)? out_grad, Tensor(g!)? out_cd")
+    lib.define(f"solve_iterate({solve_args}) -> int")
+    lib.define(f"solve_iterate_pruned({solve_args}, Tensor(h!) nn_ws, int ws_valid) -> int")
+    lib.define("icp_refine(Tensor src, Tensor tgt, Tensor? init, float max_correspondence_distance, int max_iteration, "
+               "float relative_fitness, float relative_rmse) -> (Tensor, Tensor, Tensor, Tensor)")
+    lib.define("pose_forward(Tensor params, int angle_base, int trans_mode, Tensor? src) -> (Tensor, Tensor, Tensor)")
     lib.impl("chamfer_forward", chamfer_forward, "CUDA")
     lib.impl("chamfer_backward", chamfer_backward, "CUDA")
     lib.impl("kabsch", kabsch, "CUDA")
+    lib.impl("solve_iterate", solve_iterate_out, "CUDA")
+    lib.impl("solve_iterate_pruned", solve_iterate_out, "CUDA")
+
+    def _icp(src, tgt, init, max_correspondence_distance, max_iteration, relative_fitness, relative_rmse):
+        r = icp_refine(src, tgt, init, max_correspondence_distance, max_iteration, relative_fitness, relative_rmse)
+        return r["T"], r["fitness"], r["inlier_rmse"], r["iterations"]
+
+    def _pose(params, angle_base, trans_mode, src):
+        r = pose_forward(params, angle_base, trans_mode, src)
+        return (r[0], r[1], r[2] if src is not None else params.new_empty((0,)))
+    lib.impl("icp_refine", _icp, "CUDA")
+    lib.impl("pose_forward", _pose, "CUDA")
     register_torch_ops._lib = lib      # keep alive
     _registered = True
 

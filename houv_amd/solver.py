@@ -11,8 +11,8 @@ from . import ops
 RETRY_THRESHOLD = 0.030      # houv.py:156, train_utils.py:494 (strict >)
 ITERS_PER_LAUNCH = 50        # bound single-launch duration; state round-trips through HBM (192 B/hypothesis)
 
-# bench.py sets this to a list to collect (start_event, end_event, hypotheses, iterations, N, M, use_views) per
-# houv_solve_iterate launch: HIP events recorded on the stream the kernel is launched on.
+# bench.py sets this to a list to collect (start_event, end_event, hypotheses, iterations, N, M, use_views, pruned) per
+# houv_solve_iterate[_pruned] launch: HIP events recorded on the stream the kernel is launched on.
 LAUNCH_LOG = None
 
 # the 26 non-zero {-1,0,1}^3 axes in the reference's loop order (houv.py:44-51)
@@ -49,11 +49,21 @@ def solve_twin_init_params(n_inst):
     return np.concatenate([V, a, c, s], axis=1)
 
 
-# Opt-in exact pruned nearest-neighbour search (houv_solve_iterate_pruned).  Off by default: north_star specifies the
-# brute-force sweep, and that is what bench.py measures unless --solver pruned is given.  Switch it on with
-# ``houv_amd.solver.PRUNED = True`` or HOUV_SOLVER=pruned in the environment (clouds of <= 2048 points; larger ones
-# silently take the brute-force kernel).
-PRUNED = os.environ.get("HOUV_SOLVER", "brute").strip().lower() == "pruned"
+# The DEFAULT search since round 3 is the exact pruned one (houv_solve_iterate_pruned): on the same clouds it returns the
+# brute-force sweep's result BIT FOR BIT (tests/test_gpu_solve.py::test_pruned_search_is_bit_identical_to_brute_force,
+# bench.py's `brute_force` leg compares every timed batch) at about half the time.  It wants spatially compact
+# 32-point sub-tiles, so run_stage sorts both clouds along a Morton curve first -- point order carries no meaning to
+# the loss; only the fp32 summation order changes with it.  ``houv_amd.solver.PRUNED = False`` or HOUV_SOLVER=brute
+# selects the brute-force sweep (unsorted clouds, the round-1/2 default); clouds above PRUNED_MAX_POINTS points take it
+# in any case.
+PRUNED = os.environ.get("HOUV_SOLVER", "pruned").strip().lower() != "brute"
+PRUNED_MAX_POINTS = 2048     # 64 sub-tiles of 32 points = one 64-bit visit mask per query (houv_solve_variant)
+
+
+def uses_pruned(N, M, pruned=None):
+    """Whether run_stage takes the pruned kernel for clouds of N and M points under the current / given switch."""
+    pruned = PRUNED if pruned is None else pruned
+    return bool(pruned) and max(N, M) <= PRUNED_MAX_POINTS
 
 
 def morton_sort(cloud):
@@ -167,7 +177,7 @@ def run_stage(src, tgt, params, K, n_iters, *, angle_base, trans_mode, use_views
     step = iters_per_launch or ITERS_PER_LAUNCH
     pruned = PRUNED if pruned is None else pruned
     nn_ws = None
-    if pruned and max(N, tgt.shape[1]) <= 2048:
+    if uses_pruned(N, tgt.shape[1], pruned):
         src, tgt = morton_sort(src), morton_sort(tgt)
         nn_ws = torch.empty((n, 2, 4, max(N, tgt.shape[1])), dtype=torch.int16, device=dev)
     done, out = 0, None
@@ -191,7 +201,7 @@ def run_stage(src, tgt, params, K, n_iters, *, angle_base, trans_mode, use_views
                                 ws_valid="verify" if pruned == "verify" else done > 0)
         if LAUNCH_LOG is not None:
             ev1.record(torch.cuda.current_stream(dev))
-            LAUNCH_LOG.append((ev0, ev1, n, it, N, tgt.shape[1], bool(use_views)))
+            LAUNCH_LOG.append((ev0, ev1, n, it, N, tgt.shape[1], bool(use_views), nn_ws is not None))
         done += it
     if want_last_params:
         out["last_params"] = last_params

@@ -29,6 +29,16 @@ int houv_abi_version(void);
 /* Thread-local text of the last error returned by any call below ("" if none). */
 const char* houv_last_error(void);
 
+/* sha256 (first 16 hex digits) of the sources this library was built from (houv_amd/csrc/Makefile): lets a committed
+ * profile say which build it measured.  No counterpart in the reference. */
+const char* houv_build_id(void);
+
+/* Diagnostic switches for tests, A/B scripts and bench.py (process-wide; never read from the environment).  Names and
+ * meanings: houv_amd/csrc/houv_common.h `DebugKnobs`.  Results do not depend on any of them except the ones that select
+ * an alternative kernel of the same result for timing.  Returns 0 on an unknown name / out-of-range value.
+ * No counterpart in the reference. */
+int houv_debug_set(const char* name, long long value);
+
 /* ---------------------------------------------------------------------------------------------
  * Chamfer nearest-neighbour op.
  * Replaces: pybind `chamfer_3D.forward` -> chamfer_cuda_forward

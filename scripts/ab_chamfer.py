@@ -4,7 +4,9 @@ import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
-from houv_amd import ops, synthetic
+from houv_amd import _lib, ops, synthetic
+if os.environ.get("HOUV_CHAMFER_DIRECT") == "1":   # the script's own switch -> the library's diagnostic knob
+    _lib.debug_set("chamfer_direct", 1)
 dev = torch.device("cuda:0")
 torch.manual_seed(0)   # same clouds for every variant: the checksums must agree
 out = []

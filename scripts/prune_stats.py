@@ -21,4 +21,6 @@ for views in (True, False):
     lib.houv_debug_read_prune_stats(buf, 1)
     asked, steps, slots = buf[0], buf[1], buf[2]
     print(f"views={views}: sub-tile visits asked per lane and sweep {asked/(slots*64):.1f}; wave steps per sweep {steps/slots:.1f}; "
-          f"wall kcycles per wave-sweep: bounds {buf[3]/slots/1e3:.1f}, masks {buf[4]/slots/1e3:.1f}, walk {buf[5]/slots/1e3:.1f}")
+          f"wall kcycles per wave-sweep: bounds {buf[3]/slots/1e3:.1f}, masks {buf[4]/slots/1e3:.1f}, walk {buf[5]/slots/1e3:.1f}; "
+          f"per-list wave union (64 consecutive queries) {buf[6]/(slots*4):.1f} sub-tiles (sum over the 4 lists {buf[6]/slots:.1f}), "
+          f"union over the wave's 256 queries {buf[7]/slots:.1f}")

@@ -68,7 +68,8 @@ def test_ragged_shapes_vs_oracle(dev, B, N, M):
     np.testing.assert_allclose(d2.cpu().numpy(), o2.numpy(), rtol=1e-4, atol=1e-7)
 
 
-@pytest.mark.parametrize("B,N,M", [(4, 2048, 2048), (3, 777, 1500), (2, 2500, 300), (16, 512, 512)])
+@pytest.mark.parametrize("B,N,M", [(4, 2048, 2048), (3, 777, 1500), (2, 2500, 300), (16, 512, 512),
+                                   (2, 900, 1000), (2, 1024, 700)])      # the last two: chamfer_nn_filter_kernel<4>
 def test_bit_exact_vs_c_oracle(dev, B, N, M):
     """Integer/index bar: against oracle/chamfer_ref.c (fp32 direct differences, the CUDA kernel's arithmetic with the
     same fma contraction) distances must be BIT-identical and indices exactly equal, ties included."""
@@ -86,7 +87,8 @@ def test_bit_exact_vs_c_oracle(dev, B, N, M):
 
 @pytest.mark.parametrize("B,N,M,offset,dups", [(3, 2048, 2048, 3.0, False), (2, 1500, 2048, 50.0, False),
                                                 (2, 2048, 2048, 0.0, True), (2, 900, 2600, 7.0, False),
-                                                (1, 2600, 5000, 0.0, True), (2, 2048, 2048, 1e4, False)])
+                                                (1, 2600, 5000, 0.0, True), (2, 2048, 2048, 1e4, False),
+                                                (2, 1000, 900, 3.0, False), (2, 700, 1024, 0.0, True)])    # Q = 4 loop
 def test_filter_uncertainty_paths_bit_exact(dev, B, N, M, offset, dups):
     """The expanded-form filter of chamfer_nn_filter_kernel only SELECTS candidate sub-tiles; whatever it is unsure about
     must be re-decided by the exact arithmetic.  Clouds far from the origin blow the uncertainty tau = 25 u (R+|q|)^2 up
@@ -125,6 +127,27 @@ def test_filter_and_direct_kernels_agree_on_nonfinite_inputs(dev, N, M):
     allbad = torch.full((1, 40, 3), float("nan"))
     d, _, i, _ = _cd(a[:1], allbad, dev)
     assert bool(torch.isnan(d).all()) and int(i.abs().max()) == 0
+
+
+@pytest.mark.parametrize("N,M", [(300, 500), (900, 1000), (1500, 2300)])     # Q = 2 / Q = 4 / Q = 8 with two LDS passes
+def test_huge_finite_coordinates_bit_exact(dev, N, M):
+    """beyond ~1.3e19 the filter's |r|^2 overflows (e = -inf + inf = NaN for every reference) while the direct
+    differences of chamfer3D.cu:31-36 are still finite for nearby points.  Such queries take the exact full scan: distances
+    and indices bit-identical to the C oracle, which finds d = 0 for a query sitting on a reference and 2^88-sized minima
+    elsewhere.  (2^44 is the grid on which fp32 numbers near 1e20 live.)"""
+    from oracle import c_oracle
+    gen = torch.Generator().manual_seed(N + M)
+    step = float(2 ** 44)
+    b = 1e20 + step * torch.randint(0, 40, (2, M, 3), generator=gen).float()
+    a = 1e20 + step * torch.randint(0, 40, (2, N, 3), generator=gen).float()
+    a[:, ::5] = b[:, torch.arange(0, N, 5) % M]                      # a fifth of the queries coincide with references
+    a[1, 3] = 3e38                                                     # every difference^2 overflows: reference 0, d = inf
+    d1, d2, i1, i2 = _cd(a, b, dev)
+    o1, o2, j1, j2 = c_oracle.chamfer_forward(a.numpy(), b.numpy())
+    assert np.array_equal(i1.cpu().numpy(), j1) and np.array_equal(i2.cpu().numpy(), j2)
+    assert np.array_equal(d1.cpu().numpy().view(np.uint32), o1.view(np.uint32))
+    assert np.array_equal(d2.cpu().numpy().view(np.uint32), o2.view(np.uint32))
+    assert float(d1[0, 0]) == 0.0 and bool(torch.isinf(d1[1, 3])) and int(i1[1, 3]) == 0
 
 
 def test_ties_pick_lowest_index(dev):

@@ -65,3 +65,67 @@ def test_world2_real_solve_gathers_the_single_process_result(n_pairs, mode):
     assert sorted(i for g in got for i in g[1]) == list(range(n_pairs))
     assert all(p.exitcode == 0 for p in procs)
     assert np.all(want[:, 3, :] == 0) and np.abs(want[:, :3, :3]).max() <= 1.0 + 1e-5
+
+
+def _rccl_main(q, port, src_np, tgt_np, K, iters):
+    try:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        import torch.distributed as dist
+        dev = torch.device("cuda:0")
+        torch.cuda.set_device(dev)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)        # "nccl" IS RCCL on ROCm
+        from houv_amd import distributed as hd
+        from houv_amd.models.houv import HOUV, solve_model
+        res = {}
+        # (1) the collective itself on HBM tensors, both row orders, ragged shard
+        ans = torch.zeros((5, 4, 4), device=dev)
+        ans[:, :3, :] = torch.arange(60, dtype=torch.float32, device=dev).reshape(5, 3, 4)
+        for mode in ("contiguous", "interleaved"):
+            full = hd.gather_transforms(ans, 5, mode=mode)
+            res["gather_" + mode] = bool(full.is_cuda and torch.equal(full, ans))
+        # (2) solve_sharded: real solve_model on device tensors, transforms stay in HBM through all_gather_into_tensor
+        src, tgt = torch.from_numpy(src_np).to(dev), torch.from_numpy(tgt_np).to(dev)
+
+        def solve_fn(s, t):
+            return solve_model(HOUV(s.shape[0] * K, 0), s, t, None, kernel=K, num_epochs=iters, prefix='test').to(dev)
+        want = solve_fn(src, tgt)
+        for mode in ("contiguous", "interleaved"):
+            full = hd.solve_sharded(solve_fn, src, tgt, mode=mode)
+            res["solve_" + mode] = bool(full.is_cuda and torch.equal(full, want))
+        # (3) the other two collectives bench.py uses on device tensors
+        t = torch.tensor([3.5], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.barrier()
+        res["all_reduce"] = float(t.item()) == 3.5
+        res["backend"] = dist.get_backend()
+        torch.cuda.synchronize()
+        dist.destroy_process_group()
+        q.put((res, None))
+    except Exception as e:  # pragma: no cover - reported by the parent
+        import traceback
+        q.put((None, traceback.format_exc() + repr(e)))
+
+
+def test_rccl_process_group_on_one_gpu():
+    """until a multi-GPU node runs it, execute the RCCL path at least at world size 1 on the one GPU there is:
+    init_process_group("nccl", device_id=cuda:0), all_gather_into_tensor of device-resident transforms through
+    gather_transforms / solve_sharded (both sharding modes), barrier and all_reduce -- in a child of the forkserver, so that a
+    hung collective cannot hang the suite."""
+    import multiprocessing as mp
+    import socket
+    from houv_amd import synthetic
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    src, tgt, _ = synthetic.make_pairs(5, 192, seed=77)
+    ctx = mp.get_context("forkserver")
+    q = ctx.Queue()
+    proc = ctx.Process(target=_rccl_main, args=(q, port, src.numpy(), tgt.numpy(), 26, 30))
+    proc.start()
+    res, err = q.get(timeout=300)
+    proc.join(timeout=60)
+    assert err is None, err
+    assert res["backend"] == "nccl"
+    for k in ("gather_contiguous", "gather_interleaved", "solve_contiguous", "solve_interleaved", "all_reduce"):
+        assert res[k] is True, (k, res)
+    assert proc.exitcode == 0

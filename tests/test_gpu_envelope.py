@@ -27,7 +27,7 @@ def dev():
     return torch.device("cuda:0")
 
 
-def test_golden_trajectory_2048_points(golden, dev):
+def test_golden_trajectory_2048_points(golden, dev, solver_mode):
     """G15: houv.py:106-138 on ONE 2048x2048-point pair, K=26, bases 0 and 2.  Forward n+1 of the reference reads the
     parameters after n Adam steps, so forwards 2/3/6/21 pin the 1/2/5/20-step states with G5's tolerances; the step-1
     gradient is compared like G5's."""
@@ -77,7 +77,7 @@ def _inside_envelope(gpu, env, floor, what):
 
 
 @pytest.mark.parametrize("fixture", ["g16_envelope128.npz", "g17_envelope512.npz", "g20_envelope2048.npz"])
-def test_predict_model_stays_inside_the_references_chaos_envelope(golden, dev, fixture):
+def test_predict_model_stays_inside_the_references_chaos_envelope(golden, dev, fixture, solver_mode):
     """G16 (16 pairs x 128 points) / G17 (6 pairs x 512 points, BASELINE configs[0]'s cloud size) / G20 (G15's 2048 x 2048-point
     pair: BASELINE configs[1]'s cloud size, the kernel instantiation bench.py times), K=26, base 0: predict_model
     (houv.py:106-138) at 20/50/100/200 iterations, per hypothesis, against the reference and its envelope."""
@@ -94,7 +94,7 @@ def test_predict_model_stays_inside_the_references_chaos_envelope(golden, dev, f
 
 
 @pytest.mark.parametrize("fixture", ["g18_twin_envelope.npz", "g21_twin_envelope2048.npz"])
-def test_solve_twin_stays_inside_the_references_chaos_envelope(golden, dev, fixture):
+def test_solve_twin_stays_inside_the_references_chaos_envelope(golden, dev, fixture, solver_mode):
     """G21: the same on G15's 2048 x 2048-point pair (the single-metric kernel instantiation at BASELINE configs[1]'s size).
     G18: train_utils.getPredict_angle (train_utils.py:359-456: float64 leaves from the harness-seeded global numpy RNG,
     lr 0.1, sigma = sin(s pi), loss 6 min_1) on 8 pairs x 128 points, K=26, base 1, at 5/20/50/100 iterations.  At lr 0.1

@@ -74,7 +74,7 @@ def test_single_forward_backward_vs_oracle(dev, N, M, base, mode):
     assert err.max() < 3.0 / min(N, M), err
 
 
-def test_golden_single_step_and_trajectory(golden, dev):
+def test_golden_single_step_and_trajectory(golden, dev, solver_mode):
     """G5: gradients of step 1, parameters after 1,2,5 steps (1e-5) and the 20-step horizon (loss 1e-5 / R,T 1e-4)
     against the reference's own numbers (B=2, N=256, K=16)."""
     from houv_amd import solver
@@ -114,7 +114,7 @@ def test_chunked_launches_equal_one_launch(dev):
         assert torch.equal(r[0], res[0][0]) and torch.equal(r[1], res[0][1]) and torch.equal(r[2], res[0][2])
 
 
-def test_solve_twin_short_horizon(golden, dev):
+def test_solve_twin_short_horizon(golden, dev, solver_mode):
     """G6: getPredict_angle (float64 leaves, lr 0.1, sigma = sin(s pi), loss 6*min_1), 20 iterations, harness-seeded numpy."""
     from houv_amd.train_utils import getPredict_angle
     g = golden("g6_solve.npz")
@@ -126,7 +126,7 @@ def test_solve_twin_short_horizon(golden, dev):
     np.testing.assert_allclose(Tt.cpu().numpy(), g["gpa_T"], atol=3e-2)
 
 
-def test_solve_model_end_to_end_golden(golden, dev):
+def test_solve_model_end_to_end_golden(golden, dev, solver_mode):
     """G6 end to end (3 pairs x K=16 x 30 iterations, one >=120 degree pair -> retry stage): the retry set and the
     winning transforms of the reference.  30 iterations at lr 0.01 stay within the short-horizon regime."""
     from houv_amd.models.houv import HOUV, solve_model
@@ -143,7 +143,7 @@ def test_solve_model_end_to_end_golden(golden, dev):
     assert not out.is_cuda and out.shape == (3, 4, 4)                # prefix == 'test' returns a host tensor (houv.py:199-200)
 
 
-def test_end_to_end_statistical_vs_oracle(dev):
+def test_end_to_end_statistical_vs_oracle(dev, solver_mode):
     """Top rung: full solve_model (200 iterations, retry stage) on 4 synthetic 128-pt pairs, K=26: trajectories are
     chaotic beyond ~50 iterations, so compare the distribution: the mean final score and mean RotE must agree with
     the CPU oracle's within the oracle's own sensitivity to a 1e-7 input perturbation (x3 margin, floor 0.5 deg)."""
@@ -162,7 +162,7 @@ def test_end_to_end_statistical_vs_oracle(dev):
 
 
 @pytest.mark.parametrize("fixture,frac_1e4,frac_01", [("g12_stat.npz", 0.75, 0.90), ("g13_stat512.npz", 0.30, 0.80)])
-def test_end_to_end_64_pairs_vs_reference(golden, dev, fixture, frac_1e4, frac_01):
+def test_end_to_end_64_pairs_vs_reference(golden, dev, fixture, frac_1e4, frac_01, solver_mode):
     """G12 / G13 (last gate; G13 is BASELINE configs[0]'s shape, 64 pairs x 512 points):
     solve_model over 64 synthetic pairs (K=26, 200 iterations, retry stages, 4 batches of 16) against the REAL
     reference's results on the same inputs (float64 Chamfer, autograd, torch.optim.Adam, CPU).  The best-of-K answer is
@@ -328,7 +328,7 @@ def test_unfused_loss_glue_vs_golden(golden, dev):
     np.testing.assert_allclose(gm, g["grad_moved"], atol=1e-6 * max(1.0, np.abs(g["grad_moved"]).max() * 1e3), rtol=2e-3)
 
 
-def test_solve_twin_end_to_end_vs_oracle(golden, dev):
+def test_solve_twin_end_to_end_vs_oracle(golden, dev, solver_mode):
     """a15 end to end (`solve`: base stage + retry stages, float64 leaves from the harness-seeded global numpy RNG,
     lr 0.1) at a shortened horizon (_iters=12; the reference hard-codes 500): same retry decisions and transforms as the
     oracle, to the looseness lr=0.1 imposes after a dozen steps."""
@@ -378,7 +378,7 @@ def test_gradient_direction_prediction_does_not_change_results(dev, monkeypatch,
     for the metrics A won in the PREVIOUS iteration (its sweep state is gone when the winner is known), B's for the
     metrics B wins, and a metric predicted B but won by A is repaired by redoing A for that one metric.  None of this may
     change a bit: the normal run, a run that always predicts B (every A-win takes the repair path) and a run that rescans
-    everything (HOUV_SOLVE_PREDICT, a diagnostic switch of the library) must agree exactly -- scores, losses, poses,
+    everything (houv_debug_set("solve_predict", ...), a diagnostic switch of the library) must agree exactly -- scores, losses, poses,
     gradients, the 8 Chamfer terms and the optimiser state after 40 iterations in chunks of 50 and of 7."""
     from houv_amd import solver, synthetic
     P, K = 3, 26
@@ -388,13 +388,13 @@ def test_gradient_direction_prediction_does_not_change_results(dev, monkeypatch,
     kw = dict(angle_base=0, trans_mode=tm, use_views=views, f64_params=f64, lr=0.1 if f64 else 0.01, want_grad=True,
               want_cd=True, pruned=pruned)
     runs = {}
-    for mode, chunk in ((None, 50), ("b", 50), ("all", 50), (None, 7), ("b", 7)):
-        if mode is None:
-            monkeypatch.delenv("HOUV_SOLVE_PREDICT", raising=False)
-        else:
-            monkeypatch.setenv("HOUV_SOLVE_PREDICT", mode)
-        runs[(mode, chunk)] = solver.run_stage(src, tgt, p0, K, 40, iters_per_launch=chunk, **kw)
-    monkeypatch.delenv("HOUV_SOLVE_PREDICT", raising=False)
+    from houv_amd import _lib
+    try:
+        for mode, chunk in ((None, 50), ("b", 50), ("all", 50), (None, 7), ("b", 7)):
+            _lib.debug_set("solve_predict", {None: 0, "b": 1, "all": 2}[mode])
+            runs[(mode, chunk)] = solver.run_stage(src, tgt, p0, K, 40, iters_per_launch=chunk, **kw)
+    finally:
+        _lib.debug_set("solve_predict", 0)
     ref, st_ref = runs[(None, 50)]
     for key, (out, st) in runs.items():
         for name in ("score", "loss", "R", "T", "grad", "cd"):
@@ -405,7 +405,7 @@ def test_gradient_direction_prediction_does_not_change_results(dev, monkeypatch,
     assert bool(picked_a.any()) and bool((~picked_a).any())
 
 
-def test_solve_twin_end_to_end_32_pairs_vs_reference(golden, dev):
+def test_solve_twin_end_to_end_32_pairs_vs_reference(golden, dev, solver_mode):
     """G14: the REAL reference's ``train_utils.solve`` (test.py:64's path: 500 iterations, lr 0.1, float64 leaves from the
     harness-seeded global numpy RNG, retry stages) on 32 synthetic 128-pt pairs, K=26.  At lr 0.1 the trajectories are
     chaotic (registration/README.md:82-91 calls the results non-reproducible), so per-pair answers agree only loosely
@@ -454,3 +454,47 @@ def test_concurrent_retry_stages_equal_sequential_ones(dev, monkeypatch):
     _, score, retry = solver.best_of_k_with_retry(
         lambda s, t, base: __import__("houv_amd.models.houv", fromlist=["x"]).predict_model(HOUV.blank_like(HOUV(26, 0).to(dev)), s, t, kernel=26, num_epochs=25, angle_base=base), src, tgt)
     assert 0 < retry.numel() < 12            # the workload really has a retry stage
+
+
+def test_fused_solve_through_torch_custom_ops(golden, dev):
+    """SURVEY 8(b) row 2 / VERDICT r2 #6: the fused loop is registered as PyTorch-ROCm custom ops with mutable-argument
+    schemas.  Through ``torch.ops.houv.solve_iterate`` and ``solve_iterate_pruned`` (caller-allocated outputs, state and
+    workspace updated in place, returns 1 like the C call) the 5-step G5 trajectory of the reference is reproduced, both
+    searches agree bit for bit on the same clouds, and ``pose_forward`` / ``icp_refine`` answer like their Python wrappers."""
+    from houv_amd import ops, solver
+    ops.register_torch_ops()
+    g = golden("g5_trajectory.npz")
+    s, t = solver.morton_sort(T(g["src"]).to(dev)), solver.morton_sort(T(g["tgt"]).to(dev))
+    P, N, K, n = s.shape[0], s.shape[1], 16, 32
+    res = {}
+    for pruned in (False, True):
+        state = torch.zeros((n, 24), dtype=torch.float64, device=dev)
+        state[:, :8] = T(solver.houv_init_params(n, 2021)).to(dev)
+        score, loss = torch.empty(n, device=dev), torch.empty(n, device=dev)
+        R, Tt = torch.empty((n, 3, 3), device=dev), torch.empty((n, 3), device=dev)
+        grad = torch.empty((n, 8), device=dev)
+        args = (s, t, state, K, 0, 5, 2, 0, True, False, N // 2, N, 0.01, 0.9, 0.999, 1e-8, 1.0 / n, score, loss, R, Tt, grad, None)
+        if pruned:
+            ws = torch.empty((n, 2, 4, N), dtype=torch.int16, device=dev)
+            assert torch.ops.houv.solve_iterate_pruned(*args, ws, 0) == 1
+        else:
+            assert torch.ops.houv.solve_iterate(*args) == 1
+        res[pruned] = (score.clone(), R.clone(), Tt.clone(), state.clone(), grad.clone())
+    for a, b in zip(res[False], res[True]):
+        assert torch.equal(a, b)
+    score, R, Tt, state, _ = res[True]
+    ref_p = np.concatenate([g[f"b2_n5_{k}"] for k in ("V", "angle", "tran_c", "tran_s")], 1)
+    np.testing.assert_allclose(state[:, :8].cpu().numpy(), ref_p, atol=5e-5)          # parameters after 5 Adam steps (G5's bar)
+    np.testing.assert_allclose(score.cpu().numpy(), g["b2_n5_min1"].reshape(-1), atol=1e-5)
+    np.testing.assert_allclose(R.cpu().numpy(), g["b2_n5_R"].reshape(-1, 3, 3), atol=1e-5)
+    # pose_forward / icp_refine
+    prm = state[:, :8].float().contiguous()
+    R2, T2, moved = torch.ops.houv.pose_forward(prm, 2, 0, None)
+    want = ops.pose_forward(prm, 2, 0)
+    assert torch.equal(R2, want[0]) and torch.equal(T2, want[1]) and moved.numel() == 0
+    src_k = s.repeat_interleave(K, dim=0).contiguous()
+    R3, T3, moved = torch.ops.houv.pose_forward(prm, 2, 0, src_k)
+    assert torch.allclose(moved, torch.bmm(src_k, R3.transpose(1, 2)) + T3.unsqueeze(1), atol=1e-6)
+    Ti, fit, rmse, its = torch.ops.houv.icp_refine(s, t, None, 0.02, 30, 1e-6, 1e-6)
+    w = ops.icp_refine(s, t, None, 0.02, 30, 1e-6, 1e-6)
+    assert torch.equal(Ti, w["T"]) and torch.equal(fit, w["fitness"]) and torch.equal(its, w["iterations"])
