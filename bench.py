@@ -152,8 +152,8 @@ def kernel_roofline(log, log_all, dt, all_inst_iters, n_retry_launches, stats, p
     pairs_brute = sum(n * it * 2.0 * N * M for _, _, n, it, N, M, *_ in log)          # point pairs of two full sweeps
     views = bool(log[0][6]) if log else True
     flop_pp = EXEC_FLOP_PER_PAIR[views]
-    kinds = sorted({(_lib.solve_variant(N, M, pruned), 4 if v else 1) for _, _, _, _, N, M, v, _ in log})
-    kname = ", ".join("houv::solve_kernel<%d, %d, %d, %s, 1>" % (b, q, nm, "true" if pruned else "false") for (b, q), nm in kinds)
+    kinds = sorted({(_lib.solve_variant(N, M, pruned, with_mode=True), 4 if v else 1) for _, _, _, _, N, M, v, _ in log})
+    kname = ", ".join("houv::solve_kernel<%d, %d, %d, %d, 1>" % (b, q, nm, mode) for (b, q, mode), nm in kinds)
     r = {"kernel": kname, "bound": "valu", "unit": "TFLOP/s", "peak": FP32_PEAK_TFLOPS}
     if pruned and stats and stats["pruned_wave_sweeps"]:
         # executed point pairs: every sub-tile a lane asked for = 32 evaluations (+ the brute-force first iteration of a stage)

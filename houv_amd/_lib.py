@@ -11,7 +11,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # HOUV_HIP_LIB lets the diagnostic scripts load the stamped build variant; the default is the product library
 LIB_PATH = os.environ.get("HOUV_HIP_LIB") or os.path.join(_HERE, "lib", "libhouv_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _c_f = ctypes.c_void_p     # device pointers travel as plain addresses
 _int = ctypes.c_int
@@ -32,7 +32,8 @@ _SIGNATURES = {
     "houv_solve_iterate_pruned": (ctypes.c_int, [_c_f, _c_f, _int, _int, _int, _int, _c_f, _int, _int, _int, _int, _int,
                                                  _int, _int, _int, _dbl, _dbl, _dbl, _dbl, _flt, _c_f, _c_f, _c_f, _c_f,
                                                  _c_f, _c_f, _c_f, _int, _int, _c_f]),
-    "houv_solve_variant": (ctypes.c_int, [_int, _int, _int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
+    "houv_solve_variant": (ctypes.c_int, [_int, _int, _int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int),
+                                          ctypes.POINTER(ctypes.c_int)]),
     "houv_icp_refine": (ctypes.c_int, [_c_f, _c_f, _int, _int, _int, _c_f, _flt, _int, _flt, _flt, _c_f, _c_f, _c_f, _c_f, _c_f]),
     "houv_knn": (ctypes.c_int, [_c_f, _int, _int, _int, _c_f, _c_f]),
     "houv_edgeconv1": (ctypes.c_int, [_c_f, _c_f, _int, _int, _int, _c_f, _c_f, _c_f, _c_f, _c_f]),
@@ -82,11 +83,12 @@ def load():
     return lib
 
 
-def solve_variant(N, M, pruned=False):
-    """(threads per workgroup, points per lane) of the solve_kernel that serves clouds of N and M points."""
-    b, q = ctypes.c_int(0), ctypes.c_int(0)
-    check(load().houv_solve_variant(int(N), int(M), int(bool(pruned)), ctypes.byref(b), ctypes.byref(q)), "houv_solve_variant")
-    return b.value, q.value
+def solve_variant(N, M, pruned=False, with_mode=False):
+    """(threads per workgroup, points per lane[, prune mode]) of the solve_kernel that serves clouds of N and M points."""
+    b, q, m = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
+    check(load().houv_solve_variant(int(N), int(M), int(bool(pruned)), ctypes.byref(b), ctypes.byref(q), ctypes.byref(m)),
+          "houv_solve_variant")
+    return (b.value, q.value, m.value) if with_mode else (b.value, q.value)
 
 
 def build_id():

@@ -28,14 +28,18 @@ inline bool check_launch(const char* what) {
 // independent of every switch except the two that select an alternative kernel for A/B timing (chamfer_direct, gemm_*).
 //   "solve_predict"   0 normal; 1 always predict direction B (every A-win takes the repair path); 2 rescan everything
 //   "prune_refresh"   pruned mode: every n-th iteration refreshes every remembered nearest neighbour (default 2)
+//   "prune_cap_slack" pruned walk: lock-step passes run for (mean list length of the wave + this) steps; -1 = fused loop only
 //   "solve_stats"     device address of 4 uint64 counters the fused loop's sweeps add to (0 = off): see SolveArgs::stats
+//   "prune_owner_walk" 1: the pruned search walks its sub-tile lists by owner lanes at every size (A/B against the balanced walk)
 //   "chamfer_direct"  1: houv_chamfer_forward runs the direct sweep instead of the filtered one (same bits)
 //   "chamfer_q"       queries per lane cap of the filtered Chamfer kernel (8)
 //   "gemm_4w" / "gemm_guarded"   houv_gemm_f32: 4-wave workgroups / always the guarded tile fetch
 struct DebugKnobs {
   std::atomic<int> pred_mode{0};
   std::atomic<int> ws_refresh{2};
+  std::atomic<int> prune_cap_slack{1};   // pruned walk: lock-step passes capped at the wave's mean list length + this (< 0: off)
   std::atomic<unsigned long long> stats{0ull};
+  std::atomic<int> prune_owner_walk{0};  // 1: the pruned search walks its lists by owner lanes at every size (round 2's walk)
   std::atomic<int> chamfer_direct{0};
   std::atomic<int> chamfer_q{8};
   std::atomic<int> gemm_4w{0};
@@ -92,6 +96,17 @@ __device__ __forceinline__ float wave_sum_to_lane63(float v) {
   v += dpp_f<0x118>(v);               // row_shr:8   -> lane 15 of every row of 16 holds the row sum
   v += dpp_f<0x142, 0xa>(v);          // row_bcast:15 into rows 1 and 3
   v += dpp_f<0x143, 0xc>(v);          // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave sum
+  return v;
+}
+
+// Maximum of NON-NEGATIVE ints over the 64 lanes, valid in LANE 63 ONLY (masked-out DPP sources read 0).
+__device__ __forceinline__ int wave_max_to_lane63(int v) {
+  v = max(v, dpp_i<0x111>(v));
+  v = max(v, dpp_i<0x112>(v));
+  v = max(v, dpp_i<0x114>(v));
+  v = max(v, dpp_i<0x118>(v));
+  v = max(v, dpp_i<0x142, 0xa>(v));
+  v = max(v, dpp_i<0x143, 0xc>(v));
   return v;
 }
 

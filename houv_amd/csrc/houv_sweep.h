@@ -213,17 +213,71 @@ __device__ __forceinline__ int pt_index(int k) {
 #define HOUV_PRUNE_GROUP 1
 #endif
 
-template <int BLOCK, int Q, int NMET, int OWN>
-__device__ __forceinline__ void pruned_sweep(const float4* __restrict__ refs, const float4* __restrict__ boxes, int ntile,
-                                             const float (&qx)[Q], const float (&qy)[Q], const float (&qz)[Q],
-                                             const short* __restrict__ prev, int prev_stride, int count, int rot,
-                                             float (&best)[Q][NMET], int (&btile)[Q][NMET],
-                                             unsigned long long* __restrict__ stats = nullptr) {
-  // G queries share one sub-tile list and every gathered reference (G = 1 by default, see above); a lane's Q/G lists
-  // are walked back to back inside ONE loop (a lane moves on to its next list while others are still on their first)
-  constexpr int G = (OWN < HOUV_PRUNE_GROUP) ? OWN : HOUV_PRUNE_GROUP;
-  constexpr int L = Q / G;
-  unsigned long long un[L];
+// Minimum of the NMET squared distances between G queries and the 32 references of ONE sub-tile, gathered per lane: the lane's
+// sub-tile starts at LDS byte address (xa & ~511); the scan order is rotated per lane by XOR -- reference j sits at byte
+// (j ^ rot) * 16, one v_xor per read; needs the clouds 512-B aligned in LDS (solve.hip aligns the dynamic segment),
+// conflict-free as (lane ^ j) % 16 takes 16 distinct slots in every ds_read_b128 lane group.  The reads are software-
+// pipelined: while a batch of four references is being evaluated the next batch is in flight (ping-pong register sets; the
+// trailing prefetch wraps around and is dropped).  Same expression trees as sweep_tile().
+template <int G, int NMET>
+__device__ __forceinline__ void gather_tile_min(unsigned xa, const float (&cx)[G], const float (&cy)[G], const float (&cz)[G],
+                                                float (&tm)[G][NMET]) {
+#pragma unroll
+  for (int k = 0; k < G; ++k)
+#pragma unroll
+    for (int m = 0; m < NMET; ++m) tm[k][m] = INFINITY;
+  constexpr int kBatch = 4;
+  auto fetch = [&](float4 (&r)[kBatch], int j0) {
+#pragma unroll
+    for (int u = 0; u < kBatch; ++u) {
+      const houv_f4v v = *(lds_f4)(size_t)(xa ^ ((unsigned)((j0 + u) & (kSub - 1)) << 4));
+      r[u] = make_float4(v.x, v.y, v.z, v.w);
+    }
+  };
+  auto eval = [&](float4 (&r)[kBatch]) {
+#pragma unroll
+    for (int u = 0; u < kBatch; ++u) asm volatile("" ::"v"(r[u].x), "v"(r[u].y), "v"(r[u].z), "v"(r[u].w));   // keep b128
+#pragma unroll
+    for (int u = 0; u < kBatch; u += 2) {
+      const float4 a = r[u], c = r[u + 1];
+#pragma unroll
+      for (int k = 0; k < G; ++k) {
+        const float ax = a.x - cx[k], ay = a.y - cy[k], az = a.z - cz[k];
+        const float bx = c.x - cx[k], by = c.y - cy[k], bz = c.z - cz[k];
+        if constexpr (NMET == 4) {
+          const float axx = ax * ax, ayy = ay * ay, bxx = bx * bx, byy = by * by;
+          const float a3 = __builtin_fmaf(ay, ay, axx), b3 = __builtin_fmaf(by, by, bxx);
+          const float a1 = __builtin_fmaf(az, az, ayy), b1 = __builtin_fmaf(bz, bz, byy);
+          const float a2 = __builtin_fmaf(az, az, axx), b2 = __builtin_fmaf(bz, bz, bxx);
+          const float a0 = __builtin_fmaf(az, az, a3), b0 = __builtin_fmaf(bz, bz, b3);
+          tm[k][0] = min3f(tm[k][0], a0, b0);
+          tm[k][1] = min3f(tm[k][1], a1, b1);
+          tm[k][2] = min3f(tm[k][2], a2, b2);
+          tm[k][3] = min3f(tm[k][3], a3, b3);
+        } else {
+          tm[k][0] = min3f(tm[k][0], metric_sqdist<0>(ax, ay, az), metric_sqdist<0>(bx, by, bz));
+        }
+      }
+    }
+  };
+  float4 ra[kBatch], rb[kBatch];
+  fetch(ra, 0);
+#pragma unroll 1
+  for (int j0 = 0; j0 < kSub; j0 += 2 * kBatch) {
+    fetch(rb, j0 + kBatch);
+    eval(ra);
+    fetch(ra, j0 + 2 * kBatch);
+    eval(rb);
+  }
+}
+
+// Which sub-tiles each of this lane's queries must visit: the bound per metric is the distance to the point that was the
+// query's nearest neighbour in the previous iteration (`prev`, attained), the test a point-to-box distance per metric.
+template <int BLOCK, int Q, int NMET, int OWN, int L, int G>
+__device__ __forceinline__ void prune_masks(const float4* __restrict__ refs, const float4* __restrict__ boxes, int ntile,
+                                            const float (&qx)[Q], const float (&qy)[Q], const float (&qz)[Q],
+                                            const short* __restrict__ prev, int prev_stride, int count,
+                                            unsigned long long (&un)[L]) {
 #ifdef HOUV_STAMPS
   unsigned long long pst_ = __builtin_readcyclecounter();
 #endif
@@ -260,6 +314,24 @@ __device__ __forceinline__ void pruned_sweep(const float4* __restrict__ refs, co
       }
     }
   }
+  HOUV_PSTAMP(4);
+}
+
+template <int BLOCK, int Q, int NMET, int OWN>
+__device__ __forceinline__ void pruned_sweep(const float4* __restrict__ refs, const float4* __restrict__ boxes, int ntile,
+                                             const float (&qx)[Q], const float (&qy)[Q], const float (&qz)[Q],
+                                             const short* __restrict__ prev, int prev_stride, int count, int rot,
+                                             float (&best)[Q][NMET], int (&btile)[Q][NMET],
+                                             unsigned long long* __restrict__ stats = nullptr, int cap_slack = -1) {
+  // G queries share one sub-tile list and every gathered reference (G = 1 by default, see above); a lane's Q/G lists
+  // are walked back to back inside ONE loop (a lane moves on to its next list while others are still on their first)
+  constexpr int G = (OWN < HOUV_PRUNE_GROUP) ? OWN : HOUV_PRUNE_GROUP;
+  constexpr int L = Q / G;
+  unsigned long long un[L];
+#ifdef HOUV_STAMPS
+  unsigned long long pst_ = __builtin_readcyclecounter();
+#endif
+  prune_masks<BLOCK, Q, NMET, OWN, L, G>(refs, boxes, ntile, qx, qy, qz, prev, prev_stride, count, un);
 #pragma unroll
   for (int k = 0; k < Q; ++k)
 #pragma unroll
@@ -300,9 +372,50 @@ __device__ __forceinline__ void pruned_sweep(const float4* __restrict__ refs, co
       atomicAdd(&g_prune_stat[7], (unsigned long long)__popcll(all));   // union over the whole wave
     }
   }
-  HOUV_PSTAMP(4);
+  pst_ = __builtin_readcyclecounter();
   unsigned long long steps_ = 0;
 #endif
+  // ---- capped lock-step passes (round 3) --------------------------------------------------------------------------
+  // Pass g: every lane walks ITS list g, all lanes in step, for `cap` steps (wave-uniform).  The query, its running minima
+  // and sub-tile ids are then compile-time registers: no "which list is this lane on" selects, and a lane whose list has
+  // run out simply re-evaluates its last sub-tile -- harmless, an evaluation can only repeat or exceed what `best` already
+  // holds (and a sub-tile that is NOT on a lane's list cannot hold a point at or below its bound), so no activity predicate
+  // either: 22 instead of ~110 bookkeeping instructions per step.  Pure lock-step (cap = the wave's longest list) needs
+  // 70 steps where the fused loop below needs 60 (lane imbalance); so the passes are CAPPED near the wave's mean list
+  // length and what is left of the long lists goes to the fused loop, whose steps cost more but are now few.
+  const int slack = cap_slack;
+  if (slack >= 0) {
+#pragma unroll
+    for (int g = 0; g < L; ++g) {
+      const int len = __popcll(un[g]);
+      const int wsum = __builtin_amdgcn_readlane(wave_incl_scan_dpp(len), 63);
+      const int wmax = __builtin_amdgcn_readlane(wave_max_to_lane63(len), 63);
+      const int cap = min(wmax, ((wsum + 63) >> 6) + slack);
+      float cx[G], cy[G], cz[G];
+#pragma unroll
+      for (int k = 0; k < G; ++k) { cx[k] = qx[g * G + k]; cy[k] = qy[g * G + k]; cz[k] = qz[g * G + k]; }
+      int t = 0;
+#pragma unroll 1
+      for (int s = 0; s < cap; ++s) {
+        const unsigned long long mm = un[g];
+        t = (mm != 0ull) ? (__ffsll((long long)mm) - 1) : t;
+        un[g] = mm & (mm - 1ull);                              // 0 stays 0
+        const unsigned xa = (unsigned)(size_t)(lds_f4)refs + (unsigned)t * (kSub * 16u) + ((unsigned)rot << 4);
+        float tm[G][NMET];
+        gather_tile_min<G, NMET>(xa, cx, cy, cz, tm);
+#pragma unroll
+        for (int k = 0; k < G; ++k)
+#pragma unroll
+          for (int m = 0; m < NMET; ++m) {
+            const bool lt = tm[k][m] < best[g * G + k][m];
+            best[g * G + k][m] = lt ? tm[k][m] : best[g * G + k][m];
+            btile[g * G + k][m] = lt ? t : btile[g * G + k][m];
+          }
+      }
+      nsteps += cap;
+    }
+  }
+  // ---- fused loop: whatever the passes left (everything when slack < 0) ---------------------------------------------
   for (;;) {
     // current list of this lane: the first one that still has sub-tiles
     unsigned long long mm = 0ull;
@@ -336,60 +449,9 @@ __device__ __forceinline__ void pruned_sweep(const float4* __restrict__ refs, co
         }
       }
     }
-    // scan order rotated per lane by XOR: reference j of the sub-tile sits at byte (j ^ rot) * 16 -- one v_xor per read;
-    // needs the clouds 512-B aligned in LDS (solve.hip aligns the dynamic segment), conflict-free as (lane ^ j) % 16
-    // takes 16 distinct slots in every ds_read_b128 lane group
     const unsigned xa = (unsigned)(size_t)(lds_f4)refs + (unsigned)t * (kSub * 16u) + ((unsigned)rot << 4);
     float tm[G][NMET];
-#pragma unroll
-    for (int k = 0; k < G; ++k)
-#pragma unroll
-      for (int m = 0; m < NMET; ++m) tm[k][m] = INFINITY;
-    // gathered reads are software-pipelined: while a batch of kBatch references is being evaluated the next batch is
-    // already in flight (ping-pong register sets; the trailing prefetch wraps around and is dropped)
-    constexpr int kBatch = 4;
-    auto fetch = [&](float4 (&r)[kBatch], int j0) {
-#pragma unroll
-      for (int u = 0; u < kBatch; ++u) {
-        const houv_f4v v = *(lds_f4)(size_t)(xa ^ ((unsigned)((j0 + u) & (kSub - 1)) << 4));
-        r[u] = make_float4(v.x, v.y, v.z, v.w);
-      }
-    };
-    auto eval = [&](float4 (&r)[kBatch]) {
-#pragma unroll
-      for (int u = 0; u < kBatch; ++u) asm volatile("" ::"v"(r[u].x), "v"(r[u].y), "v"(r[u].z), "v"(r[u].w));   // keep b128
-#pragma unroll
-      for (int u = 0; u < kBatch; u += 2) {
-        const float4 a = r[u], c = r[u + 1];
-#pragma unroll
-        for (int k = 0; k < G; ++k) {
-          const float ax = a.x - cx[k], ay = a.y - cy[k], az = a.z - cz[k];
-          const float bx = c.x - cx[k], by = c.y - cy[k], bz = c.z - cz[k];
-          if constexpr (NMET == 4) {
-            const float axx = ax * ax, ayy = ay * ay, bxx = bx * bx, byy = by * by;
-            const float a3 = __builtin_fmaf(ay, ay, axx), b3 = __builtin_fmaf(by, by, bxx);
-            const float a1 = __builtin_fmaf(az, az, ayy), b1 = __builtin_fmaf(bz, bz, byy);
-            const float a2 = __builtin_fmaf(az, az, axx), b2 = __builtin_fmaf(bz, bz, bxx);
-            const float a0 = __builtin_fmaf(az, az, a3), b0 = __builtin_fmaf(bz, bz, b3);
-            tm[k][0] = min3f(tm[k][0], a0, b0);
-            tm[k][1] = min3f(tm[k][1], a1, b1);
-            tm[k][2] = min3f(tm[k][2], a2, b2);
-            tm[k][3] = min3f(tm[k][3], a3, b3);
-          } else {
-            tm[k][0] = min3f(tm[k][0], metric_sqdist<0>(ax, ay, az), metric_sqdist<0>(bx, by, bz));
-          }
-        }
-      }
-    };
-    float4 ra[kBatch], rb[kBatch];
-    fetch(ra, 0);
-#pragma unroll 1
-    for (int j0 = 0; j0 < kSub; j0 += 2 * kBatch) {
-      fetch(rb, j0 + kBatch);
-      eval(ra);
-      fetch(ra, j0 + 2 * kBatch);
-      eval(rb);
-    }
+    gather_tile_min<G, NMET>(xa, cx, cy, cz, tm);
 #pragma unroll
     for (int g = 0; g < L; ++g)
 #pragma unroll
@@ -406,6 +468,146 @@ __device__ __forceinline__ void pruned_sweep(const float4* __restrict__ refs, co
   if ((threadIdx.x & 63) == 0) atomicAdd(&g_prune_stat[1], steps_);
   HOUV_PSTAMP(5);
 #endif
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Pruned sweep, BALANCED form (round 3; solve_kernel<.., PRUNE = 2>).  The owner-walk above loses ~20 % of its steps to
+// lane imbalance (a wave runs for its longest lane) and ~25 % of its instructions to "which of my lists am I on" selects.
+// Here the walk is detached from ownership:
+//   1. every thread computes the visit masks of ITS queries (prune_masks) and parks them in LDS -- in the .w lanes of the
+//      two clouds' float4 slots, which nothing else uses (8 bytes per point index: exactly one 64-bit mask);
+//   2. the workgroup's queries are counting-sorted by list length, longest first (65 bins, LDS atomics, 2 bytes per query);
+//   3. waves take blocks of 64 consecutive sorted queries from a shared counter (longest blocks first: LPT scheduling); the
+//      64 lists of a block have (nearly) the same length, so all lanes walk in lock-step with no idle lanes, the query, its
+//      running minima and sub-tile ids in fixed registers (~22 bookkeeping instructions per step instead of ~110); a lane
+//      whose list is a step shorter re-evaluates its last sub-tile, which cannot change its result;
+//   4. per query the sub-tile ids of the minima go back to the owner through the query's (now consumed) mask slot, the four
+//      minima through a per-hypothesis scratch record in global memory (16 bytes per query; L2-resident).
+// A query's sub-tiles are still visited in ascending order with strict <, so (best, btile) are bit-identical to sweep().
+// LDS cost: 2 bytes per query + 0.5 KB, so two 512-thread workgroups still share a CU (the phases of one hide behind
+// the sweeps of the other: a single 1024-thread workgroup per CU measured 14 % slower on the brute-force kernel).
+// ---------------------------------------------------------------------------------------------------------------
+struct SortedStage {
+  unsigned short* order;      // [BLOCK * Q]  query ids, longest list first
+  int* hist;                  // [65 + 65 + 2]  bin counts (by 64 - length) | bin bases | next block
+};
+
+__device__ __forceinline__ unsigned& w_slot(float4* cloud, int q) { return reinterpret_cast<unsigned*>(cloud + q)[3]; }
+
+// wlo / whi: the two LDS clouds (both hold >= count entries); .w of wlo[q] carries the low half of query q's mask and,
+// after the walk, the sub-tile ids of its minima; .w of whi[q] the high half.
+template <int BLOCK, int Q, int NMET>
+__device__ __forceinline__ void pruned_sweep_sorted(const float4* __restrict__ refs, const float4* __restrict__ boxes, int ntile,
+                                                    const float4* __restrict__ qarr, float4* wlo, float4* whi,
+                                                    const float (&qx)[Q], const float (&qy)[Q], const float (&qz)[Q],
+                                                    const short* __restrict__ prev, int prev_stride, int count, int rot,
+                                                    const SortedStage& st, float4* __restrict__ res, float (&best)[Q][NMET],
+                                                    int (&btile)[Q][NMET], unsigned long long* __restrict__ stats) {
+  static_assert(BLOCK % 64 == 0 && BLOCK >= 128, "the bin prefix runs on one wave while another resets the block counter");
+  const int tid = threadIdx.x, lane = tid & 63;
+  unsigned long long un[Q];
+  prune_masks<BLOCK, Q, NMET, 1, Q, 1>(refs, boxes, ntile, qx, qy, qz, prev, prev_stride, count, un);
+  int len[Q], rnk[Q];
+#pragma unroll
+  for (int k = 0; k < Q; ++k) {
+    const int q = pt_index<BLOCK, Q, 1>(k);
+    len[k] = __popcll(un[k]);
+    rnk[k] = 0;
+    if (q < count) {
+      w_slot(wlo, q) = (unsigned)un[k];
+      w_slot(whi, q) = (unsigned)(un[k] >> 32);
+      rnk[k] = atomicAdd(&st.hist[64 - len[k]], 1);        // place inside its bin (any order: results do not depend on it)
+    }
+  }
+  __syncthreads();
+  if (tid < 64) {                                           // exclusive prefix over the 65 bins, then clear them for the next sweep
+    const int c = st.hist[tid];
+    const int incl = wave_incl_scan_dpp(c);
+    st.hist[65 + tid] = incl - c;
+    if (tid == 63) st.hist[65 + 64] = incl;                 // bin 64 = empty lists (cannot happen for a valid query; harmless)
+    st.hist[tid] = 0;
+    if (tid == 0) st.hist[64] = 0;
+  } else if (tid == 64) {
+    st.hist[130] = 0;                                       // next block
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < Q; ++k) {
+    const int q = pt_index<BLOCK, Q, 1>(k);
+    if (q < count) st.order[st.hist[65 + 64 - len[k]] + rnk[k]] = (unsigned short)q;
+  }
+  __syncthreads();
+  const int nblk = (count + 63) >> 6;
+  int asked = 0, nsteps = 0;
+  for (;;) {
+    int b = 0;
+    if (lane == 0) b = atomicAdd(&st.hist[130], 1);
+    b = __builtin_amdgcn_readfirstlane(b);
+    if (b >= nblk) break;
+    const int e = b * 64 + lane;
+    const bool valid = e < count;                                       // the last block may be partly filled
+    const int q = st.order[valid ? e : count - 1];
+    unsigned long long mm = valid ? (((unsigned long long)w_slot(whi, q) << 32) | w_slot(wlo, q)) : 0ull;
+    const int cap = __builtin_amdgcn_readfirstlane(__popcll(mm));      // sorted: lane 0 holds the block's longest list
+    const float4 qp = qarr[q];
+    float cx[1] = {qp.x}, cy[1] = {qp.y}, cz[1] = {qp.z};
+    float cb[NMET];
+    int ct[NMET];
+#pragma unroll
+    for (int m = 0; m < NMET; ++m) { cb[m] = INFINITY; ct[m] = 0; }
+    asked += __popcll(mm);
+    nsteps += cap;
+    int t = 0;
+#pragma unroll 1
+    for (int s = 0; s < cap; ++s) {
+      t = (mm != 0ull) ? (__ffsll((long long)mm) - 1) : t;
+      mm &= mm - 1ull;                                                  // 0 stays 0
+      const unsigned xa = (unsigned)(size_t)(lds_f4)refs + (unsigned)t * (kSub * 16u) + ((unsigned)rot << 4);
+      float tm[1][NMET];
+      gather_tile_min<1, NMET>(xa, cx, cy, cz, tm);
+#pragma unroll
+      for (int m = 0; m < NMET; ++m) {
+        const bool lt = tm[0][m] < cb[m];
+        cb[m] = lt ? tm[0][m] : cb[m];
+        ct[m] = lt ? t : ct[m];
+      }
+    }
+    if (valid) {
+      if constexpr (NMET == 4) {
+        res[q] = make_float4(cb[0], cb[1], cb[2], cb[3]);
+        w_slot(wlo, q) = (unsigned)ct[0] | ((unsigned)ct[1] << 8) | ((unsigned)ct[2] << 16) | ((unsigned)ct[3] << 24);
+      } else {
+        res[q].x = cb[0];
+        w_slot(wlo, q) = (unsigned)ct[0];
+      }
+    }
+  }
+  if (stats) {
+    asked = wave_incl_scan_dpp(asked);
+    if (lane == 63) atomicAdd(&stats[0], (unsigned long long)asked);
+    if (lane == 0) {
+      atomicAdd(&stats[1], (unsigned long long)nsteps);
+      atomicAdd(&stats[2], 1ull);                                       // one wave-sweep = 64 x Q queries, as in the owner walk
+    }
+  }
+  __syncthreads();   // the workgroup's waves share one L1: its global stores above are visible to its loads below
+#pragma unroll
+  for (int k = 0; k < Q; ++k) {
+    const int q = pt_index<BLOCK, Q, 1>(k);
+    const bool ok = q < count && len[k] > 0;                            // padding queries were never walked
+    const int qq = ok ? q : 0;
+    const unsigned tl = w_slot(wlo, qq);
+    if constexpr (NMET == 4) {
+      const float4 r = res[qq];
+      best[k][0] = ok ? r.x : INFINITY; best[k][1] = ok ? r.y : INFINITY; best[k][2] = ok ? r.z : INFINITY; best[k][3] = ok ? r.w : INFINITY;
+      btile[k][0] = ok ? (int)(tl & 255u) : 0; btile[k][1] = ok ? (int)((tl >> 8) & 255u) : 0;
+      btile[k][2] = ok ? (int)((tl >> 16) & 255u) : 0; btile[k][3] = ok ? (int)(tl >> 24) : 0;
+    } else {
+      const float r = res[qq].x;
+      best[k][0] = ok ? r : INFINITY;
+      btile[k][0] = ok ? (int)(tl & 255u) : 0;
+    }
+  }
 }
 
 // Axis-aligned boxes of the 32-point sub-tiles of a cloud whose points live in this lane's registers (ownership as

@@ -43,12 +43,14 @@ struct SolveArgs {
   float* out_T;
   float* out_grad;
   float* out_cd;
-  short* nn_ws;      // pruned mode: [P*K][2 dirs][4 metrics][ws_stride] index of each query's NN in the last iteration
+  short* nn_ws;      // pruned mode, per hypothesis 16 rows of ws_stride int16: rows [dir*4 + metric] = index of each query's NN
+                     // in the last iteration; rows 8..15 = ws_stride float4 of scratch (the balanced walk's minima per query)
   int ws_valid;      //   1: nn_ws holds the NNs of the iteration before this launch's first one
   int ws_stride;
   int pred_mode;     // diagnostics (HOUV_SOLVE_PREDICT): 0 normal; 1 always predict direction B (every A-win takes the
                      // repair path); 2 rescan everything (no skipping: the round-1 epilogue's work)
   int ws_refresh;    // pruned mode: every ws_refresh-th iteration rescans everything (refreshes every remembered NN)
+  int cap_slack;     // pruned walk: lock-step passes capped at the wave's mean list length + cap_slack (< 0: fused loop only)
   unsigned long long* stats;   // houv_debug_set("solve_stats", device pointer): [0] sub-tile visits the lanes of the pruned sweeps
                                // asked for, [1] sub-tile steps their waves executed, [2] pruned wave-sweeps, [3] brute wave-sweeps,
                                // [4] shader clocks (s_memtime) and [5] 100-MHz ticks (s_memrealtime) summed over the workgroups'
@@ -93,17 +95,24 @@ struct Smem {
   int* ctl;        // [8 + NW]
   float4* tbox;    // [2*64] lo/hi boxes of the target's 32-point sub-tiles   (pruned mode only)
   float4* mbox;    // [2*64] same for the moved cloud, rebuilt every iteration
+  SortedStage st;  // staging of the balanced pruned sweep (PRUNE == 2 only)
 };
 
-__host__ __device__ inline size_t smem_bytes(int N, int M, int block, bool prune) {
-  const int npad = (N + kSub - 1) / kSub * kSub, mpad = (M + kSub - 1) / kSub * kSub;
+// prune: 0 brute force, 1 pruned (owner walk), 2 pruned (balanced walk: + staging for block * q queries)
+__host__ __device__ inline size_t smem_bytes(int N, int M, int block, int prune, int q) {
+  int npad = (N + kSub - 1) / kSub * kSub, mpad = (M + kSub - 1) / kSub * kSub;
+  if (prune == 2) npad = mpad = (npad > mpad ? npad : mpad);   // the balanced walk parks a mask half in EITHER cloud's .w lanes
   const int nw = block / 64;
+  const size_t nq = (size_t)block * q;
   return (size_t)(npad + mpad) * 16 + 24 * 8 + 12 * 4 + 8 * kAccStride * 4 + (size_t)2 * nw * kRedStride * 4 +
-         kHistSets * kHistBins * 4 + (8 + nw) * 4 + 64 + (prune ? 2 * 128 * 16 : 0);
+         kHistSets * kHistBins * 4 + (8 + nw) * 4 + 64 + (prune ? 2 * 128 * 16 : 0) +
+         (prune == 2 ? nq * 2 + 132 * 4 : 0);
 }
 
-__device__ inline Smem carve(unsigned char* base, int N, int M, int block) {
-  const int npad = (N + kSub - 1) / kSub * kSub, mpad = (M + kSub - 1) / kSub * kSub;
+// nq = BLOCK * Q for the balanced pruned sweep (PRUNE == 2), 0 otherwise
+__device__ inline Smem carve(unsigned char* base, int N, int M, int block, int nq) {
+  int npad = (N + kSub - 1) / kSub * kSub, mpad = (M + kSub - 1) / kSub * kSub;
+  if (nq) npad = mpad = (npad > mpad ? npad : mpad);
   const int nw = block / 64;
   Smem s;
   s.tgt = reinterpret_cast<float4*>(base);
@@ -119,6 +128,9 @@ __device__ inline Smem carve(unsigned char* base, int N, int M, int block) {
   const size_t box_off = ((size_t)(reinterpret_cast<unsigned char*>(s.ctl + 8 + nw) - base) + 15) & ~(size_t)15;
   s.tbox = reinterpret_cast<float4*>(base + box_off);
   s.mbox = s.tbox + 128;
+  // balanced pruned sweep only (the pointers are never used otherwise)
+  s.st.hist = reinterpret_cast<int*>(s.mbox + 128);
+  s.st.order = reinterpret_cast<unsigned short*>(s.st.hist + 132);
   return s;
 }
 
@@ -422,11 +434,12 @@ __device__ __forceinline__ void repair_direction_a(const Smem& sm, const float* 
 // PRUNE: the exact pruned search of houv_sweep.h.  OWN: a lane owns Q/OWN chunks of OWN consecutive points (pt_index);
 // 1 (strided, coalesced loads) everywhere by default -- other values are build-time experiments of the pruned mode
 // (HOUV_PRUNE_OWN), for which <PRUNE=false, OWN> is the brute-force sweep under the same summation order (ws_valid=-1).
-template <int BLOCK, int Q, int NMET, bool PRUNE, int OWN>
+template <int BLOCK, int Q, int NMET, int PRUNE, int OWN>
 __global__ __launch_bounds__(BLOCK, 4) void solve_kernel(SolveArgs a) {
+  static_assert(PRUNE != 2 || OWN == 1, "the balanced pruned sweep keeps the strided point ownership");
   extern __shared__ __attribute__((aligned(512))) unsigned char smem_raw[];   // 512 B: pruned_sweep's XOR-rotated gathers
   const int N = a.N, M = a.M;
-  const Smem sm = carve(smem_raw, N, M, BLOCK);
+  const Smem sm = carve(smem_raw, N, M, BLOCK, PRUNE == 2 ? BLOCK * Q : 0);
   const int tid = threadIdx.x;
   const int ninst = a.P * a.K;
   // XCD-aware placement: workgroups b and b+8 share an XCD (and its L2), so give each XCD a contiguous
@@ -443,14 +456,19 @@ __global__ __launch_bounds__(BLOCK, 4) void solve_kernel(SolveArgs a) {
   for (int j = N + tid; j < npad; j += BLOCK) sm.mov[j] = pad4;
   if (tid < 24) sm.state[tid] = a.state[(size_t)inst * 24 + tid];
   for (int j = tid; j < kHistBins; j += BLOCK) sm.hist[j] = 0u;   // radix-select histogram set 0 (select_smallest rotates)
+  if constexpr (PRUNE == 2) {
+    if (tid < 132) sm.st.hist[tid] = 0;                           // list-length bins of the balanced pruned sweep
+  }
   int hrot = 0;
   __syncthreads();
   const int rot = tid & (kSub - 1);
   short* ws_a = nullptr;   // NN of the moved points in the target (direction 1)
   short* ws_b = nullptr;   // NN of the target points in the moved cloud (direction 0)
+  float4* ws_res = nullptr;   // balanced walk: per-query minima on their way back to the owning lanes
   if constexpr (PRUNE) {
-    ws_b = a.nn_ws + ((size_t)inst * 2 + 0) * 4 * a.ws_stride;
-    ws_a = a.nn_ws + ((size_t)inst * 2 + 1) * 4 * a.ws_stride;
+    ws_b = a.nn_ws + ((size_t)inst * 16 + 0) * a.ws_stride;
+    ws_a = a.nn_ws + ((size_t)inst * 16 + 4) * a.ws_stride;
+    ws_res = reinterpret_cast<float4*>(a.nn_ws + ((size_t)inst * 16 + 8) * a.ws_stride);
     float tx0[Q], ty0[Q], tz0[Q];
 #pragma unroll
     for (int k = 0; k < Q; ++k) {
@@ -497,7 +515,7 @@ __global__ __launch_bounds__(BLOCK, 4) void solve_kernel(SolveArgs a) {
     float best[Q][NMET];
     int btile[Q][NMET];
     if (a.pred_mode == 1) pred_a = 0u;
-    const bool allgrad = a.pred_mode == 2 || (PRUNE && (a.ws_refresh <= 1 || ((a.steps_done + it) % a.ws_refresh) == 0 ||
+    const bool allgrad = a.pred_mode == 2 || ((PRUNE != 0) && (a.ws_refresh <= 1 || ((a.steps_done + it) % a.ws_refresh) == 0 ||
                                                         (a.ws_valid == 0 && it == 0)));
     const unsigned grad_a = allgrad ? kAllMet : pred_a;
     {
@@ -530,8 +548,11 @@ __global__ __launch_bounds__(BLOCK, 4) void solve_kernel(SolveArgs a) {
         pruned_now = (a.ws_valid != 0) || (it > 0);
       }
       if (pruned_now) {
-        if constexpr (PRUNE) {
-          pruned_sweep<BLOCK, Q, NMET, OWN>(sm.tgt, sm.tbox, mpad / kSub, mx, my, mz, ws_a, a.ws_stride, N, rot, best, btile, a.stats);
+        if constexpr (PRUNE == 2) {
+          pruned_sweep_sorted<BLOCK, Q, NMET>(sm.tgt, sm.tbox, mpad / kSub, sm.mov, sm.tgt, sm.mov, mx, my, mz, ws_a, a.ws_stride, N,
+                                              rot, sm.st, ws_res, best, btile, a.stats);
+        } else if constexpr (PRUNE == 1) {
+          pruned_sweep<BLOCK, Q, NMET, OWN>(sm.tgt, sm.tbox, mpad / kSub, mx, my, mz, ws_a, a.ws_stride, N, rot, best, btile, a.stats, a.cap_slack);
         }
       } else {
         sweep<Q, NMET>(sm.tgt, mpad / kSub, mx, my, mz, best, btile);
@@ -560,10 +581,13 @@ __global__ __launch_bounds__(BLOCK, 4) void solve_kernel(SolveArgs a) {
         const float4 v = (i < M) ? sm.tgt[i] : make_float4(0.f, 0.f, 0.f, 0.f);
         tx[k] = v.x; ty[k] = v.y; tz[k] = v.z;
       }
-      const bool pruned_now = PRUNE && ((a.ws_valid != 0) || (it > 0));
+      const bool pruned_now = (PRUNE != 0) && ((a.ws_valid != 0) || (it > 0));
       if (pruned_now) {
-        if constexpr (PRUNE) {
-          pruned_sweep<BLOCK, Q, NMET, OWN>(sm.mov, sm.mbox, npad / kSub, tx, ty, tz, ws_b, a.ws_stride, M, rot, best, btile, a.stats);
+        if constexpr (PRUNE == 2) {
+          pruned_sweep_sorted<BLOCK, Q, NMET>(sm.mov, sm.mbox, npad / kSub, sm.tgt, sm.tgt, sm.mov, tx, ty, tz, ws_b, a.ws_stride, M,
+                                              rot, sm.st, ws_res, best, btile, a.stats);
+        } else if constexpr (PRUNE == 1) {
+          pruned_sweep<BLOCK, Q, NMET, OWN>(sm.mov, sm.mbox, npad / kSub, tx, ty, tz, ws_b, a.ws_stride, M, rot, best, btile, a.stats, a.cap_slack);
         }
       } else {
         sweep<Q, NMET>(sm.mov, npad / kSub, tx, ty, tz, best, btile);
@@ -695,9 +719,9 @@ __global__ __launch_bounds__(BLOCK, 4) void solve_kernel(SolveArgs a) {
   }
 }
 
-template <int BLOCK, int Q, bool PRUNE, int OWN>
+template <int BLOCK, int Q, int PRUNE, int OWN>
 int launch(const SolveArgs& a, int use_views, hipStream_t s) {
-  const size_t bytes = smem_bytes(a.N, a.M, BLOCK, PRUNE);
+  const size_t bytes = smem_bytes(a.N, a.M, BLOCK, PRUNE, Q);
   const int grid = a.P * a.K;
   hipError_t e;
   if (use_views) {
@@ -741,10 +765,13 @@ extern "C" int houv_debug_read_stamps(unsigned long long* host_out, int reset) {
 constexpr int kOwn2 = HOUV_PRUNE_OWN < 2 ? HOUV_PRUNE_OWN : 2;
 constexpr int kOwn4 = HOUV_PRUNE_OWN;
 
-// The variant table: which solve_kernel<BLOCK, Q> serves clouds of max(N, M) points.  Q = 3 points per lane covers the
-// sizes between the powers of two without idle lanes (768, 1536, 3072).  tests/test_host_logic.py enumerates this table
-// and fails when a variant has no size that the GPU tests compare with the CPU oracle.
-extern "C" int houv_solve_variant(int N, int M, int pruned, int* block, int* points_per_lane) {
+// The variant table: which solve_kernel<BLOCK, Q> serves clouds of max(N, M) points -- the SAME (BLOCK, Q) for the brute-force
+// sweep and for the pruned search, so that both sum in the same order and agree bit for bit.  Q = 3 points per lane covers
+// the sizes between the powers of two without idle lanes (768, 1536, 3072).  The pruned search walks its sub-tile lists
+// balanced (PRUNE = 2, pruned_sweep_sorted) where a workgroup has at least 3 blocks of 64 queries per wave to deal out
+// (Q >= 3), by owner lanes (PRUNE = 1) below.  tests/test_host_logic.py enumerates this table and fails when a variant
+// has no size that the GPU tests compare with the CPU oracle.
+extern "C" int houv_solve_variant(int N, int M, int pruned, int* block, int* points_per_lane, int* prune_mode) {
   using namespace houv;
   const int mx = N > M ? N : M;
   if (N <= 0 || M <= 0) {
@@ -770,6 +797,7 @@ extern "C" int houv_solve_variant(int N, int M, int pruned, int* block, int* poi
   else { b = 1024; q = 4; }
   if (block) *block = b;
   if (points_per_lane) *points_per_lane = q;
+  if (prune_mode) *prune_mode = !pruned ? 0 : ((q >= 3 && !g_debug.prune_owner_walk.load()) ? 2 : 1);
   return 1;
 }
 
@@ -802,36 +830,36 @@ static int solve_dispatch(const float* src, const float* tgt, int P, int N, int 
   }
   // pruned mode refreshes every remembered NN on every 2nd iteration (same-device A/B, profiles/r02_ab_pruned_refresh.txt:
   // 1 -> 0.988, 2 -> 0.960, 4 -> 0.963, 8 -> 0.990, never -> 1.09 us per hypothesis-iteration; results identical in all).
-  // pred_mode / ws_refresh / stats are diagnostics set through houv_debug_set(), never through the environment.
+  // pred_mode / ws_refresh / cap_slack / stats are diagnostics set through houv_debug_set(), never through the environment.
   SolveArgs a{src, tgt, P, N, M, K, state, steps_done, n_iters, angle_base, trans_mode, f64_params, k_full, k_view,
               lr, beta1, beta2, eps, loss_scale, out_score, out_loss, out_R, out_T, out_grad, out_cd, nn_ws, ws_valid,
-              ws_stride, g_debug.pred_mode.load(), g_debug.ws_refresh.load(),
+              ws_stride, g_debug.pred_mode.load(), g_debug.ws_refresh.load(), g_debug.prune_cap_slack.load(),
               reinterpret_cast<unsigned long long*>(g_debug.stats.load())};
   hipStream_t s = (hipStream_t)stream;
   const int mx = N > M ? N : M;
-  int block = 0, q = 0;
-  if (!houv_solve_variant(N, M, prune ? 1 : 0, &block, &q)) return 0;
-  if (prune && (!nn_ws || ws_stride < mx)) {
-    set_error("%s: pruned mode needs a workspace (ws_stride >= max(N,M))", who);
+  int block = 0, q = 0, mode = 0;
+  if (!houv_solve_variant(N, M, prune ? 1 : 0, &block, &q, &mode)) return 0;
+  if (prune && (!nn_ws || ws_stride < mx || (ws_stride & 7))) {
+    set_error("%s: pruned mode needs a workspace of 16 x ws_stride int16 per hypothesis, ws_stride >= max(N,M) and a multiple of 8", who);
     return 0;
   }
-  bool verify = false;
-  if (prune && ws_valid < 0) {   // test aid: the brute-force sweep under the pruned kernel's point ownership / summation order
+  if (prune && ws_valid < 0) {   // test aid: the pruned entry point with the search switched off = the brute-force kernel of this size
     a.ws_valid = 0;
-    verify = true;
+    mode = 0;
   }
-  // one instantiation per row of the variant table (houv_solve_variant), x {views, no views}
+  // one instantiation per row of the variant table (houv_solve_variant), x {views, no views}, x {brute force, pruned}
 #define HOUV_GO(B_, Q_, OWN_)                                                    \
   if (block == B_ && q == Q_) {                                                  \
-    if (prune && !verify) return launch<B_, Q_, true, OWN_>(a, use_views, s);    \
-    return launch<B_, Q_, false, OWN_>(a, use_views, s);                         \
+    if (mode == 2) return launch<B_, Q_, (Q_ >= 3 ? 2 : 1), 1>(a, use_views, s); \
+    if (mode == 1) return launch<B_, Q_, 1, OWN_>(a, use_views, s);              \
+    return launch<B_, Q_, 0, OWN_>(a, use_views, s);                             \
   }
-  if (prune) {
+  if (mx <= 2048) {
     HOUV_GO(256, 1, 1) HOUV_GO(256, 2, kOwn2) HOUV_GO(256, 3, 1) HOUV_GO(256, 4, kOwn4)
     HOUV_GO(512, 3, 1) HOUV_GO(512, 4, kOwn4)
   } else {
-    HOUV_GO(256, 1, 1) HOUV_GO(256, 2, 1) HOUV_GO(256, 3, 1) HOUV_GO(256, 4, 1)
-    HOUV_GO(512, 3, 1) HOUV_GO(512, 4, 1) HOUV_GO(1024, 3, 1) HOUV_GO(1024, 4, 1)
+    if (block == 1024 && q == 3) return launch<1024, 3, 0, 1>(a, use_views, s);
+    if (block == 1024 && q == 4) return launch<1024, 4, 0, 1>(a, use_views, s);
   }
 #undef HOUV_GO
   set_error("%s: no kernel variant <%d,%d>", who, block, q);

@@ -121,13 +121,20 @@ def solve_iterate_out(src, tgt, state, K, steps_done, n_iters, angle_base, trans
     with torch.cuda.device(src.device):
         if nn_ws is None:
             ok = _lib.load().houv_solve_iterate(*common, _lib.stream_of(src))
-        else:   # exact pruned search: nn_ws int16 [P*K, 2, 4, stride] persists between chunked launches
-            if nn_ws.dtype != torch.int16 or tuple(nn_ws.shape[:3]) != (n, 2, 4) or not nn_ws.is_contiguous():
-                raise _lib.HouvHipError("solve_iterate: nn_ws must be a contiguous int16 [P*K,2,4,stride] tensor")
-            ok = _lib.load().houv_solve_iterate_pruned(*common, _lib.ptr(nn_ws), int(ws_valid), nn_ws.shape[3],
+        else:   # exact pruned search: nn_ws int16 [P*K, 16, stride] (solve_workspace) persists between chunked launches
+            if nn_ws.dtype != torch.int16 or nn_ws.dim() != 3 or tuple(nn_ws.shape[:2]) != (n, 16) or not nn_ws.is_contiguous():
+                raise _lib.HouvHipError("solve_iterate: nn_ws must be a contiguous int16 [P*K,16,stride] tensor (ops.solve_workspace)")
+            ok = _lib.load().houv_solve_iterate_pruned(*common, _lib.ptr(nn_ws), int(ws_valid), nn_ws.shape[2],
                                                        _lib.stream_of(src))
     _lib.check(ok, "houv_solve_iterate" + ("_pruned" if nn_ws is not None else ""))
     return 1
+
+
+def solve_workspace(n_hypotheses, N, M, device):
+    """Workspace of houv_solve_iterate_pruned for n hypotheses on clouds of N and M points: int16 [n, 16, stride] (rows 0..7
+    the remembered nearest neighbours per direction and metric, rows 8..15 scratch), stride = max(N, M) rounded up to 8."""
+    stride = (max(int(N), int(M)) + 7) // 8 * 8
+    return torch.empty((int(n_hypotheses), 16, stride), dtype=torch.int16, device=device)
 
 
 def solve_iterate(src, tgt, state, K, *, steps_done, n_iters, angle_base, trans_mode, use_views, f64_params, k_full,

@@ -179,7 +179,7 @@ def run_stage(src, tgt, params, K, n_iters, *, angle_base, trans_mode, use_views
     nn_ws = None
     if uses_pruned(N, tgt.shape[1], pruned):
         src, tgt = morton_sort(src), morton_sort(tgt)
-        nn_ws = torch.empty((n, 2, 4, max(N, tgt.shape[1])), dtype=torch.int16, device=dev)
+        nn_ws = ops.solve_workspace(n, N, tgt.shape[1], dev)
     done, out = 0, None
     last_params = None
     while done < n_iters:

@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define HOUV_ABI_VERSION 1
+#define HOUV_ABI_VERSION 2
 
 /* ABI version of the loaded library (== HOUV_ABI_VERSION). */
 int houv_abi_version(void);
@@ -107,7 +107,9 @@ int houv_solve_iterate(const float* src, const float* tgt, int P, int N, int M, 
  * attained upper bound, and 32-point sub-tiles whose bounding box lies farther than the bound for all metrics are
  * skipped.  Works best on spatially sorted clouds (houv_amd.solver sorts them along a Morton curve).  The search result
  * and the summation order are those of houv_solve_iterate: same outputs BIT FOR BIT when given the same clouds.
- *   nn_ws[P*K, 2, 4, ws_stride] int16  workspace, in/out (previous NN index per hypothesis / direction / metric / point)
+ *   nn_ws[P*K, 16, ws_stride] int16  workspace, in/out, opaque to the caller: per hypothesis rows [dir*4 + metric] hold the
+ *              previous nearest-neighbour index of every point, rows 8..15 are scratch (ws_stride x 16 bytes);
+ *              ws_stride >= max(N, M) and a multiple of 8
  *   ws_valid   0: nn_ws holds nothing yet (the first iteration of this call runs the brute-force sweep)
  *              1: nn_ws was left by the previous call on the same hypotheses (chunked launches)
  *             -1: verification mode: every iteration runs the brute-force sweep (nn_ws is not used)
@@ -122,11 +124,13 @@ int houv_solve_iterate_pruned(const float* src, const float* tgt, int P, int N, 
                               int16_t* nn_ws, int ws_valid, int ws_stride, void* stream);
 
 /* Which kernel variant the two entry points above launch for clouds of N and M points (host-only query, no GPU work):
- * *block = threads per workgroup (256 / 512 / 1024), *points_per_lane = query points a lane owns (1..4).  Returns 0
- * with houv_last_error() set when no variant serves the size (max(N,M) > 4096; pruned != 0: max(N,M) > 2048).
+ * *block = threads per workgroup (256 / 512 / 1024), *points_per_lane = query points a lane owns (1..4), *prune_mode =
+ * 0 brute-force sweep, 1 pruned search walked by the owning lanes, 2 pruned search with the balanced (sorted-block) walk --
+ * the template arguments of houv::solve_kernel<block, points_per_lane, metrics, prune_mode, 1>.  Any out pointer may be NULL.
+ * Returns 0 with houv_last_error() set when no variant serves the size (max(N,M) > 4096; pruned != 0: max(N,M) > 2048).
  * No counterpart in the reference (its kernel has one fixed launch shape, chamfer3D.cu:142-143); exported so that
  * the test-suite can prove that every variant is compared with the CPU oracle. */
-int houv_solve_variant(int N, int M, int pruned, int* block, int* points_per_lane);
+int houv_solve_variant(int N, int M, int pruned, int* block, int* points_per_lane, int* prune_mode);
 
 /* ---------------------------------------------------------------------------------------------
  * Point-to-point ICP refinement, one pair per workgroup (BASELINE configs[3]).

@@ -13,6 +13,9 @@ p0 = solver.houv_init_params(P * K)
 solver.PRUNED = bool(int(os.environ.get('PRUNED', '0')))
 src, tgt = solver.morton_sort(src), solver.morton_sort(tgt)
 lib = _lib.load()
+if os.environ.get("OWNER_WALK") == "1":
+    _lib.debug_set("prune_owner_walk", 1)
+NW = _lib.solve_variant(N, N, solver.PRUNED)[0] // 64        # waves per workgroup of the variant that runs
 buf = (ctypes.c_ulonglong * 16)()
 for views in (True, False):
     solver.run_stage(src, tgt, p0, K, 2, angle_base=0, trans_mode=0, use_views=views, f64_params=False, lr=0.01)
@@ -26,8 +29,8 @@ for views in (True, False):
     v = np.array(list(buf), dtype=np.float64)
     names = ["move+sync", "sweepA", "epilogueA", "sweepB", "epilogueB", "barrier", "tail+sync", "-"]
     tot = v[:7].sum()
-    per = v / (P * K * iters * 8)     # per wave per iteration
-    print(f"views={views}: {e0.elapsed_time(e1):.1f} ms, {e0.elapsed_time(e1)*1e3/(P*K*iters):.3f} us/hyp-iter")
+    per = v / (P * K * iters * NW)     # per wave per iteration
+    print(f"views={views} pruned={solver.PRUNED} waves/WG={NW}: {e0.elapsed_time(e1):.1f} ms, {e0.elapsed_time(e1)*1e3/(P*K*iters):.3f} us/hyp-iter")
     for n, x, y in zip(names[:7], v[:7], per[:7]):
         print(f"   {n:10s} {100*x/tot:5.1f} %   {y/1e3:8.1f} kcycles per wave-iteration")
     for n, i in (("  epi:select", 9), ("  epi:rescan+sums+wave-reduce", 8), ("  epi:barrier+final-sum", 11)):

@@ -24,7 +24,7 @@ PRUNED_CASES = [
     (700, 700, True, False, 0), (768, 600, False, True, 1),    # <256,3>
     (1000, 1000, True, False, 0), (900, 1024, False, True, 1),  # <256,4>
     (1400, 1400, True, False, 0), (1000, 1300, False, True, 1),  # <512,3>
-    (2048, 2048, True, False, 0), (2048, 1700, False, True, 1),  # <512,4>
+    (2048, 2048, True, False, 0), (2048, 1700, False, True, 1),  # <512,4>, balanced walk
 ]
 
 

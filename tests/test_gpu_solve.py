@@ -475,7 +475,7 @@ def test_fused_solve_through_torch_custom_ops(golden, dev):
         grad = torch.empty((n, 8), device=dev)
         args = (s, t, state, K, 0, 5, 2, 0, True, False, N // 2, N, 0.01, 0.9, 0.999, 1e-8, 1.0 / n, score, loss, R, Tt, grad, None)
         if pruned:
-            ws = torch.empty((n, 2, 4, N), dtype=torch.int16, device=dev)
+            ws = ops.solve_workspace(n, N, N, dev)
             assert torch.ops.houv.solve_iterate_pruned(*args, ws, 0) == 1
         else:
             assert torch.ops.houv.solve_iterate(*args) == 1

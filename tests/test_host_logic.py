@@ -154,7 +154,11 @@ def test_every_solve_kernel_variant_is_oracle_compared():
     from solve_cases import ORACLE_CASES, PRUNED_CASES
     table = {_lib.solve_variant(n, n) for n in range(1, 4097)}
     assert table == {(256, 1), (256, 2), (256, 3), (256, 4), (512, 3), (512, 4), (1024, 3), (1024, 4)}
-    assert _lib.solve_variant(2048, 2048) == (512, 4)            # the kernel bench.py times (BASELINE configs[1])
+    assert _lib.solve_variant(2048, 2048) == (512, 4)            # the kernels bench.py times (BASELINE configs[1]) ...
+    assert _lib.solve_variant(2048, 2048, pruned=True, with_mode=True) == (512, 4, 2)     # ... the pruned one with the balanced walk
+    assert _lib.solve_variant(2048, 2048, with_mode=True) == (512, 4, 0) and _lib.solve_variant(400, 400, True, True) == (256, 2, 1)
+    # brute force and pruned search use the SAME (block, points per lane) at every size: same summation order, same bits
+    assert all(_lib.solve_variant(n, n) == _lib.solve_variant(n, n, pruned=True) for n in range(1, 2049))
     assert _lib.solve_variant(100, 3000) == (1024, 3)            # the larger cloud decides
     covered = {(_lib.solve_variant(N, M), 4 if mode == "houv" else 1) for N, M, _, mode in ORACLE_CASES}
     missing = {(v, nmet) for v in table for nmet in (4, 1)} - covered
