@@ -20,6 +20,7 @@
 //   * top-k (k = N/2 for the full metric) = exact 4-pass 8-bit radix select on the fp32 bit patterns
 //     of the register-resident distances, LDS histogram;
 //   * the un-moved source point needed for sum G p^T in the target->moved direction is R^T(p' - T).
+#include <stddef.h>
 #include <stdlib.h>
 
 #include "../../include/houv_hip.h"
@@ -83,12 +84,15 @@ constexpr int kAccN = 13;      // sum sqrt(d), G[3], (G p^T)[9]
 constexpr int kRedStride = 4 * kAccN;   // per-wave partial sums of one direction: [metric][13]
 constexpr int kHistBins = 256;          // 8-bit radix digits
 constexpr int kHistSets = 3;            // rotating histograms: one barrier per radix pass (see select_smallest)
+constexpr int kPoseFloats = 28;         // sizeof(Pose) / 4 rounded up
+static_assert(sizeof(Pose) <= kPoseFloats * 4 && offsetof(Pose, T) == 36, "sm.pose[0..11] must be R | T");
 
 struct Smem {
   float4* tgt;     // [Mpad]
   float4* mov;     // [Npad]
   double* state;   // [24]
-  float* pose;     // [12] R row-major, T
+  double* adam;    // [2][2] step size and sqrt(bias correction 2) of Adam: slot = step parity (see the scalar tail)
+  float* pose;     // [kPoseFloats] the whole Pose of the current parameters: R row-major [0..8], T [9..11], backward intermediates
   float* acc;      // [8][kAccStride]   slot = metric*2 + dir
   float* red;      // [2 dirs][NW][kRedStride]
   unsigned* hist;  // [kHistSets][256]
@@ -104,7 +108,7 @@ __host__ __device__ inline size_t smem_bytes(int N, int M, int block, int prune,
   if (prune == 2) npad = mpad = (npad > mpad ? npad : mpad);   // the balanced walk parks a mask half in EITHER cloud's .w lanes
   const int nw = block / 64;
   const size_t nq = (size_t)block * q;
-  return (size_t)(npad + mpad) * 16 + 24 * 8 + 12 * 4 + 8 * kAccStride * 4 + (size_t)2 * nw * kRedStride * 4 +
+  return (size_t)(npad + mpad) * 16 + 28 * 8 + kPoseFloats * 4 + 8 * kAccStride * 4 + (size_t)2 * nw * kRedStride * 4 +
          kHistSets * kHistBins * 4 + (8 + nw) * 4 + 64 + (prune ? 2 * 128 * 16 : 0) +
          (prune == 2 ? nq * 2 + 132 * 4 : 0);
 }
@@ -118,8 +122,9 @@ __device__ inline Smem carve(unsigned char* base, int N, int M, int block, int n
   s.tgt = reinterpret_cast<float4*>(base);
   s.mov = s.tgt + mpad;
   s.state = reinterpret_cast<double*>(s.mov + npad);
-  s.pose = reinterpret_cast<float*>(s.state + 24);
-  s.acc = s.pose + 12;
+  s.adam = s.state + 24;
+  s.pose = reinterpret_cast<float*>(s.adam + 4);
+  s.acc = s.pose + kPoseFloats;
   s.red = s.acc + 8 * kAccStride;
   s.hist = reinterpret_cast<unsigned*>(s.red + 2 * nw * kRedStride);
   s.ctl = reinterpret_cast<int*>(s.hist + kHistSets * kHistBins);
@@ -132,6 +137,17 @@ __device__ inline Smem carve(unsigned char* base, int N, int M, int block, int n
   s.st.hist = reinterpret_cast<int*>(s.mbox + 128);
   s.st.order = reinterpret_cast<unsigned short*>(s.st.hist + 132);
   return s;
+}
+
+__device__ __forceinline__ void store_pose(float* dst, const Pose& f) {
+  const float* src = reinterpret_cast<const float*>(&f);
+#pragma unroll
+  for (int i = 0; i < (int)(sizeof(Pose) / 4); ++i) dst[i] = src[i];
+}
+__device__ __forceinline__ void load_pose(Pose& f, const float* src) {
+  float* dst = reinterpret_cast<float*>(&f);
+#pragma unroll
+  for (int i = 0; i < (int)(sizeof(Pose) / 4); ++i) dst[i] = src[i];
 }
 
 // Exact selection of the `ksel` smallest of the BLOCK*Q keys (fp32 bit patterns of non-negative
@@ -478,16 +494,22 @@ __global__ __launch_bounds__(BLOCK, 4) void solve_kernel(SolveArgs a) {
     }
     tile_boxes<BLOCK, Q, OWN>(tx0, ty0, tz0, M, mpad / kSub, sm.tbox);   // the target is static: boxes once per launch
   }
+  // Adam's step-dependent scalars (two double pow()) are computed off the critical path: by thread kAdamTid (another wave,
+  // hence another SIMD, when the workgroup has one) one iteration ahead, into the slot of the step's parity.
+  constexpr int kAdamTid = BLOCK >= 128 ? 64 : 0;
   if (tid == 0) {
     float p[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) p[k] = (float)sm.state[k];
     Pose f;
     pose_forward(p, a.angle_base, a.trans_mode, f);
-#pragma unroll
-    for (int k = 0; k < 9; ++k) sm.pose[k] = f.R[k];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) sm.pose[9 + k] = f.T[k];
+    store_pose(sm.pose, f);
+  }
+  if (tid == kAdamTid) {
+    const int step = a.steps_done + 1;
+    const AdamScalars asc = adam_scalars(step, a.lr, a.beta1, a.beta2);
+    sm.adam[(step & 1) * 2 + 0] = asc.step_size;
+    sm.adam[(step & 1) * 2 + 1] = asc.bc2_sqrt;
   }
   __syncthreads();
 
@@ -635,12 +657,16 @@ __global__ __launch_bounds__(BLOCK, 4) void solve_kernel(SolveArgs a) {
     HOUV_STAMP(5);
 
     // ---- per-hypothesis scalar tail: loss, closed-form gradient, Adam, next pose ----
+    if (kAdamTid != 0 && tid == kAdamTid && it + 1 < a.n_iters) {   // next iteration's Adam scalars, while thread 0 works below
+      const int step = a.steps_done + it + 2;
+      const AdamScalars asc = adam_scalars(step, a.lr, a.beta1, a.beta2);
+      sm.adam[(step & 1) * 2 + 0] = asc.step_size;
+      sm.adam[(step & 1) * 2 + 1] = asc.bc2_sqrt;
+    }
     if (tid == 0) {
       float p[8];
-#pragma unroll
-      for (int k = 0; k < 8; ++k) p[k] = (float)sm.state[k];
       Pose f;
-      pose_forward(p, a.angle_base, a.trans_mode, f);
+      load_pose(f, sm.pose);        // the forward of the current parameters, kept from the end of the previous tail / the prologue
       float cd[NMET][2], val[NMET];
       int pick[NMET];
       float gT[3] = {0.f, 0.f, 0.f}, Mm[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -687,7 +713,7 @@ __global__ __launch_bounds__(BLOCK, 4) void solve_kernel(SolveArgs a) {
             for (int d = 0; d < 2; ++d) a.out_cd[(size_t)inst * 8 + m * 2 + d] = (m < NMET) ? cd[m < NMET ? m : 0][d] : 0.f;
       }
       const int step = a.steps_done + it + 1;
-      const AdamScalars asc = adam_scalars(step, a.lr, a.beta1, a.beta2);   // two double pow() per step, not per parameter
+      const AdamScalars asc{sm.adam[(step & 1) * 2 + 0], sm.adam[(step & 1) * 2 + 1]};
       if (a.f64_params) {
         for (int k = 0; k < 8; ++k)
           adam_step<double>(sm.state[k], sm.state[8 + k], sm.state[16 + k], (double)g[k], asc, a.beta1, a.beta2, a.eps);
@@ -701,10 +727,12 @@ __global__ __launch_bounds__(BLOCK, 4) void solve_kernel(SolveArgs a) {
 #pragma unroll
       for (int k = 0; k < 8; ++k) p[k] = (float)sm.state[k];
       pose_forward(p, a.angle_base, a.trans_mode, f);
-#pragma unroll
-      for (int k = 0; k < 9; ++k) sm.pose[k] = f.R[k];
-#pragma unroll
-      for (int k = 0; k < 3; ++k) sm.pose[9 + k] = f.T[k];
+      store_pose(sm.pose, f);
+      if (kAdamTid == 0 && it + 1 < a.n_iters) {                       // single-wave workgroups: no other wave to do it
+        const AdamScalars nxt = adam_scalars(step + 1, a.lr, a.beta1, a.beta2);
+        sm.adam[((step + 1) & 1) * 2 + 0] = nxt.step_size;
+        sm.adam[((step + 1) & 1) * 2 + 1] = nxt.bc2_sqrt;
+      }
     }
     __syncthreads();
     HOUV_STAMP(6);
@@ -762,7 +790,6 @@ extern "C" int houv_debug_read_stamps(unsigned long long* host_out, int reset) {
 #ifndef HOUV_PRUNE_OWN
 #define HOUV_PRUNE_OWN 1
 #endif
-constexpr int kOwn2 = HOUV_PRUNE_OWN < 2 ? HOUV_PRUNE_OWN : 2;
 constexpr int kOwn4 = HOUV_PRUNE_OWN;
 
 // The variant table: which solve_kernel<BLOCK, Q> serves clouds of max(N, M) points -- the SAME (BLOCK, Q) for the brute-force
@@ -787,7 +814,9 @@ extern "C" int houv_solve_variant(int N, int M, int pruned, int* block, int* poi
     return 0;
   }
   int b, q;
-  if (mx <= 256) { b = 256; q = 1; }
+  if (mx <= 64) { b = 64; q = 1; }            // small clouds: no idle waves (every wave runs the whole epilogue, points or not)
+  else if (mx <= 128) { b = 128; q = 1; }
+  else if (mx <= 256) { b = 256; q = 1; }
   else if (mx <= 512) { b = 256; q = 2; }
   else if (mx <= 768) { b = 256; q = 3; }
   else if (mx <= 1024) { b = 256; q = 4; }
@@ -797,7 +826,9 @@ extern "C" int houv_solve_variant(int N, int M, int pruned, int* block, int* poi
   else { b = 1024; q = 4; }
   if (block) *block = b;
   if (points_per_lane) *points_per_lane = q;
-  if (prune_mode) *prune_mode = !pruned ? 0 : ((q >= 3 && !g_debug.prune_owner_walk.load()) ? 2 : 1);
+  // Up to 512 points the pruned search does not pay (profiles/r03_sizes.txt: 16 sub-tiles or fewer, the bounds, box tests
+  // and lists cost more than they save): houv_solve_iterate_pruned then runs the brute-force kernel -- the same result.
+  if (prune_mode) *prune_mode = (!pruned || q < 3) ? 0 : ((b == 512 && q == 4 && g_debug.prune_owner_walk.load()) ? 1 : 2);
   return 1;
 }
 
@@ -847,16 +878,17 @@ static int solve_dispatch(const float* src, const float* tgt, int P, int N, int 
     a.ws_valid = 0;
     mode = 0;
   }
+  if (mode == 0) a.nn_ws = nullptr;
   // one instantiation per row of the variant table (houv_solve_variant), x {views, no views}, x {brute force, pruned}
-#define HOUV_GO(B_, Q_, OWN_)                                                    \
+#define HOUV_GO(B_, Q_)                                                          \
   if (block == B_ && q == Q_) {                                                  \
-    if (mode == 2) return launch<B_, Q_, (Q_ >= 3 ? 2 : 1), 1>(a, use_views, s); \
-    if (mode == 1) return launch<B_, Q_, 1, OWN_>(a, use_views, s);              \
-    return launch<B_, Q_, 0, OWN_>(a, use_views, s);                             \
+    if (mode == 2) return launch<B_, Q_, (Q_ >= 3 ? 2 : 0), 1>(a, use_views, s); \
+    return launch<B_, Q_, 0, 1>(a, use_views, s);                                \
   }
   if (mx <= 2048) {
-    HOUV_GO(256, 1, 1) HOUV_GO(256, 2, kOwn2) HOUV_GO(256, 3, 1) HOUV_GO(256, 4, kOwn4)
-    HOUV_GO(512, 3, 1) HOUV_GO(512, 4, kOwn4)
+    if (mode == 1) return launch<512, 4, 1, kOwn4>(a, use_views, s);   // round 2's owner walk, A/B only (prune_owner_walk)
+    HOUV_GO(64, 1) HOUV_GO(128, 1) HOUV_GO(256, 1) HOUV_GO(256, 2) HOUV_GO(256, 3) HOUV_GO(256, 4)
+    HOUV_GO(512, 3) HOUV_GO(512, 4)
   } else {
     if (block == 1024 && q == 3) return launch<1024, 3, 0, 1>(a, use_views, s);
     if (block == 1024 && q == 4) return launch<1024, 4, 0, 1>(a, use_views, s);

@@ -8,8 +8,9 @@
   compact new-style groups (link messages), contiguous / compact / chunked (B-tree v1) layouts, deflate, shuffle and
   fletcher32 filters, fixed-point and IEEE float types of either byte order.
 
-Not supported (raises ``H5FormatError``): dense groups (fractal heap), v4 chunk indexes other than single-chunk /
-implicit, strings / compounds / references, external or virtual storage.  Format: "HDF5 File Format Specification
+Chunk indexes of the v4 layout (``libver='latest'``): single-chunk, implicit, fixed array, and -- for resizable datasets --
+extensible array (one unlimited dimension) and v2 B-tree (several).  Not supported (raises ``H5FormatError``): strings /
+compounds / references, external or virtual storage.  Format: "HDF5 File Format Specification
 Version 3.0".  tests/test_hdf5_min.py checks both directions against fixtures produced with libhdf5 1.10.6 and, where
 the image has them, against ``h5dump`` / ``libhdf5.so`` themselves."""
 import mmap
@@ -61,11 +62,12 @@ class Dataset:
     def __init__(self, f, name, msgs):
         self._f, self.name = f, name
         self.shape = self.dtype = None
+        self.maxshape = None
         self._layout = None
         self._filters = []
         for typ, data in msgs:
             if typ == 0x0001:
-                self.shape = self._parse_space(data)
+                self.shape, self.maxshape = self._parse_space(data)
             elif typ == 0x0003:
                 self.dtype = _parse_datatype(data)
             elif typ == 0x0008:
@@ -87,7 +89,12 @@ class Dataset:
             off = 4
         else:
             raise H5FormatError("dataspace message version %d" % ver)
-        return tuple(int.from_bytes(b[off + 8 * i:off + 8 * i + 8], "little") for i in range(rank))
+        dims = tuple(int.from_bytes(b[off + 8 * i:off + 8 * i + 8], "little") for i in range(rank))
+        maxd = dims
+        if flags & 1:         # maximum dimensions present (UNDEF = unlimited)
+            off += 8 * rank
+            maxd = tuple(int.from_bytes(b[off + 8 * i:off + 8 * i + 8], "little") for i in range(rank))
+        return dims, maxd
 
     def _parse_layout(self, b):
         ver = b[0]
@@ -120,8 +127,11 @@ class Dataset:
                     return ("implicit", int.from_bytes(b[p:p + 8], "little"), tuple(dims[:-1]), dims[-1])
                 if idx == 3:      # fixed array
                     return ("farray", int.from_bytes(b[p + 1:p + 9], "little"), tuple(dims[:-1]), dims[-1])
-                raise H5FormatError("%s: chunk index type %d (extensible array / v2 B-tree: resizable datasets) is not "
-                                    "supported" % (self.name, idx))
+                if idx == 4:      # extensible array (one unlimited dimension): 5 creation parameters, then the header address
+                    return ("earray", int.from_bytes(b[p + 5:p + 13], "little"), tuple(dims[:-1]), dims[-1])
+                if idx == 5:      # v2 B-tree (two or more unlimited dimensions): node size (4), split %, merge %, header address
+                    return ("btree2", int.from_bytes(b[p + 6:p + 14], "little"), tuple(dims[:-1]), dims[-1])
+                raise H5FormatError("%s: chunk index type %d is not supported" % (self.name, idx))
             raise H5FormatError("%s: layout class %d" % (self.name, cls))
         if ver in (1, 2):     # libhdf5 < 1.6.3: dims follow the address; for chunked storage the last one is the element size
             nd, cls = b[1], b[2]
@@ -283,7 +293,178 @@ class Dataset:
         if kind == "farray":
             yield from self._fixed_array(root, lo, hi)
             return
+        if kind == "earray":
+            yield from self._ext_array(root, lo, hi)
+            return
+        if kind == "btree2":
+            yield from self._btree2(root, lo, hi)
+            return
         yield from self._walk(root, lo, hi)
+
+    # -- extensible array (HDF5 File Format Specification 3.0, VII.D; libhdf5 H5EA*.c) ------------------------------
+    # Element i lives: in the index block for i < idx_blk_elmts; otherwise in a data block of super block u, which holds
+    # 2^(u/2) data blocks of dblk_min * 2^((u+1)/2) elements.  The index block addresses the data blocks of the first
+    # 2*log2(sup_blk_min_data_ptrs) super blocks directly, the other super blocks through EASB blocks.  A data block with
+    # more than 2^page_bits elements keeps them in pages (each with its own checksum) behind its prefix.
+    def _ext_array(self, addr, lo, hi):
+        mm, base = self._f._mm, self._f._base
+        u64 = lambda q, n=8: int.from_bytes(mm[q:q + n], "little")
+        h = base + addr
+        if mm[h:h + 4] != b"EAHD" or mm[h + 4] != 0:
+            raise H5FormatError("%s: bad extensible-array header" % self.name)
+        filtered, esz, max_bits, idx_elmts = mm[h + 5] == 1, mm[h + 6], mm[h + 7], mm[h + 8]
+        dblk_min, sup_min_ptrs, page_bits = mm[h + 9], mm[h + 10], mm[h + 11]
+        max_idx_set = u64(h + 12 + 8 * 4)                       # statistics: 6 lengths, the 5th = highest index set + 1
+        iblk = u64(h + 12 + 8 * 6)
+        if iblk == UNDEF:
+            return
+        ib = base + iblk
+        if mm[ib:ib + 4] != b"EAIB":
+            raise H5FormatError("%s: bad extensible-array index block" % self.name)
+        off_size = (max_bits + 7) // 8
+        log2 = lambda x: x.bit_length() - 1
+        nsblks = 1 + (max_bits - log2(dblk_min))
+        ib_nsblks = 2 * log2(sup_min_ptrs)
+        ndblk_addrs = 2 * (sup_min_ptrs - 1)
+        per_page = 1 << page_bits
+        cdims = self._layout[2]
+        cbytes = int(np.prod(cdims, dtype=np.int64)) * self.dtype.itemsize
+        # chunk coordinates of a linear index: the unlimited dimension is the slowest one ("swizzled" when it is not dim 0)
+        rank = len(self.shape)
+        unlim = [i for i, m in enumerate(self.maxshape) if m == UNDEF]
+        if len(unlim) != 1:
+            raise H5FormatError("%s: extensible-array index without exactly one unlimited dimension" % self.name)
+        ud = unlim[0]
+        order = [ud] + [i for i in range(rank) if i != ud]
+        maxc = [-(-self.maxshape[i] // cdims[i]) if self.maxshape[i] != UNDEF else None for i in range(rank)]
+        down = {}
+        acc = 1
+        for i in reversed(order):
+            down[i] = acc
+            acc *= (maxc[i] if maxc[i] is not None else 1)
+
+        def coords(i):
+            out = [0] * rank
+            for d in order:
+                out[d], i = divmod(i, down[d])
+            return tuple(k * c for k, c in zip(out, cdims))
+
+        def emit(i, e):
+            caddr = u64(e)
+            if caddr == UNDEF or i >= max_idx_set:
+                return None
+            offs = coords(i)
+            if any(o >= s for o, s in zip(offs, self.shape)) or not (offs[0] < hi and offs[0] + cdims[0] > lo):
+                return None
+            if filtered:
+                return offs, caddr, u64(e + 8, esz - 12), u64(e + esz - 4, 4)
+            return offs, caddr, cbytes, 0
+
+        def data_block(daddr, first, nelmts):
+            d = base + daddr
+            if mm[d:d + 4] != b"EADB":
+                raise H5FormatError("%s: bad extensible-array data block" % self.name)
+            q = d + 6 + 8 + off_size                         # signature, version, client, header address, block offset
+            if nelmts > per_page:                            # paged: prefix checksum, then pages of per_page elements + checksum
+                q += 4
+                for i in range(nelmts):
+                    yield first + i, q + i * esz + (i // per_page) * 4
+            else:
+                for i in range(nelmts):
+                    yield first + i, q + i * esz
+
+        q = ib + 6 + 8
+        for i in range(idx_elmts):
+            r = emit(i, q + i * esz)
+            if r:
+                yield r
+        q += idx_elmts * esz
+        dblk_addrs = [u64(q + 8 * i) for i in range(ndblk_addrs)]
+        q += 8 * ndblk_addrs
+        sblk_addrs = [u64(q + 8 * i) for i in range(max(nsblks - ib_nsblks, 0))]
+        start, k = idx_elmts, 0
+        for u in range(nsblks):
+            ndblks, dn = 1 << (u // 2), dblk_min << ((u + 1) // 2)
+            if start >= max_idx_set:
+                break
+            if u < ib_nsblks:
+                addrs = dblk_addrs[k:k + ndblks]
+                k += ndblks
+            else:
+                sa = sblk_addrs[u - ib_nsblks]
+                addrs = [UNDEF] * ndblks
+                if sa != UNDEF:
+                    sb = base + sa
+                    if mm[sb:sb + 4] != b"EASB":
+                        raise H5FormatError("%s: bad extensible-array super block" % self.name)
+                    p2 = sb + 6 + 8 + off_size
+                    if dn > per_page:                        # page-initialisation bitmaps of its (paged) data blocks
+                        p2 += ndblks * ((dn // per_page + 7) // 8)
+                    addrs = [u64(p2 + 8 * j) for j in range(ndblks)]
+            for j, da in enumerate(addrs):
+                if da != UNDEF:
+                    for i, e in data_block(da, start + j * dn, dn):
+                        r = emit(i, e)
+                        if r:
+                            yield r
+            start += ndblks * dn
+
+    # -- v2 B-tree chunk index (specification III.A.2, record types 10 / 11; libhdf5 H5B2*.c, H5Dbtree2.c) ------------
+    def _btree2(self, addr, lo, hi):
+        mm, base = self._f._mm, self._f._base
+        u64 = lambda q, n=8: int.from_bytes(mm[q:q + n], "little")
+        h = base + addr
+        if mm[h:h + 4] != b"BTHD" or mm[h + 4] != 0:
+            raise H5FormatError("%s: bad v2 B-tree header" % self.name)
+        rtype, node_size, rec_size, depth = mm[h + 5], u64(h + 6, 4), u64(h + 10, 2), u64(h + 12, 2)
+        if rtype not in (10, 11):
+            raise H5FormatError("%s: v2 B-tree of record type %d is not a chunk index" % (self.name, rtype))
+        root, root_nrec = u64(h + 16), u64(h + 24, 2)
+        if root == UNDEF or root_nrec == 0:
+            return
+        rank = len(self.shape)
+        cdims = self._layout[2]
+        cbytes = int(np.prod(cdims, dtype=np.int64)) * self.dtype.itemsize
+        enc = lambda limit: (max(int(limit), 1).bit_length() - 1) // 8 + 1          # H5VM_limit_enc_size
+        max_nrec = [(node_size - 10) // rec_size]                                    # per depth: leaf first
+        cum_max, cum_size = [max_nrec[0]], [0]
+        nrec_size = enc(max_nrec[0])
+        for d in range(1, depth + 1):
+            ptr = 8 + nrec_size + cum_size[d - 1]
+            max_nrec.append((node_size - (10 + ptr)) // (rec_size + ptr))
+            cum_max.append((max_nrec[d] + 1) * cum_max[d - 1] + max_nrec[d])
+            cum_size.append(enc(cum_max[d]))
+
+        def record(q):
+            caddr = u64(q)
+            if rtype == 11:
+                size_len = rec_size - 8 - 4 - 8 * rank
+                size, mask, q2 = u64(q + 8, size_len), u64(q + 8 + size_len, 4), q + 12 + size_len
+            else:
+                size, mask, q2 = cbytes, 0, q + 8
+            offs = tuple(u64(q2 + 8 * i) * cdims[i] for i in range(rank))            # scaled (chunk) coordinates
+            if caddr != UNDEF and offs[0] < hi and offs[0] + cdims[0] > lo:
+                return offs, caddr, size, mask
+            return None
+
+        def node(naddr, nrec, d):
+            n = base + naddr
+            sig = b"BTIN" if d > 0 else b"BTLF"
+            if mm[n:n + 4] != sig:
+                raise H5FormatError("%s: bad v2 B-tree node" % self.name)
+            q = n + 6
+            for i in range(nrec):
+                r = record(q + i * rec_size)
+                if r:
+                    yield r
+            if d > 0:
+                q += nrec * rec_size
+                ptr = 8 + nrec_size + cum_size[d - 1]
+                for i in range(nrec + 1):
+                    c = q + i * ptr
+                    yield from node(u64(c), u64(c + 8, nrec_size), d - 1)
+
+        yield from node(root, root_nrec, depth)
 
     def _fixed_array(self, addr, lo, hi):
         mm, base = self._f._mm, self._f._base

@@ -58,12 +58,14 @@ def solve_twin_init_params(n_inst):
 # in any case.
 PRUNED = os.environ.get("HOUV_SOLVER", "pruned").strip().lower() != "brute"
 PRUNED_MAX_POINTS = 2048     # 64 sub-tiles of 32 points = one 64-bit visit mask per query (houv_solve_variant)
+PRUNED_MIN_POINTS = 513      # up to 512 points (16 sub-tiles) the search costs more than it saves: the library itself runs
+                             # the brute-force kernel there (houv_solve_variant reports prune mode 0; profiles/r03_sizes.txt)
 
 
 def uses_pruned(N, M, pruned=None):
     """Whether run_stage takes the pruned kernel for clouds of N and M points under the current / given switch."""
     pruned = PRUNED if pruned is None else pruned
-    return bool(pruned) and max(N, M) <= PRUNED_MAX_POINTS
+    return bool(pruned) and PRUNED_MIN_POINTS <= max(N, M) <= PRUNED_MAX_POINTS
 
 
 def morton_sort(cloud):

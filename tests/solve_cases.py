@@ -4,10 +4,13 @@ test that enumerates the kernel variant table (test_host_logic.py) and fails whe
 ORACLE_CASES: (N, M, angle_base, mode) -- mode "houv" runs solve_kernel<.., NMET=4> (HOUV module: view terms on, fp32 Adam),
 "solve" runs <.., NMET=1> (train_utils.solve twin: no views, float64 leaves).
 PRUNED_CASES: (N, M, views, f64_params, trans_mode) -- the pruned kernels are compared BIT FOR BIT with the brute-force
-kernel of the same variant, which in turn is compared with the oracle above."""
+kernel of the same variant, which in turn is compared with the oracle above.  Up to 512 points the library serves the
+pruned entry point with the brute-force kernel (prune mode 0): those sizes check exactly that."""
 
 ORACLE_CASES = [
-    (128, 128, 0, "houv"), (96, 160, 1, "solve"),              # <256,1>
+    (64, 64, 3, "houv"), (40, 64, 1, "solve"),                 # <64,1>
+    (128, 128, 0, "houv"), (100, 128, 2, "solve"),             # <128,1>
+    (200, 200, 1, "houv"), (96, 160, 1, "solve"),              # <256,1>
     (400, 400, 2, "houv"), (300, 300, 3, "solve"),             # <256,2>
     (600, 600, 0, "houv"), (700, 640, 2, "solve"),             # <256,3>
     (1000, 1000, 2, "houv"), (900, 1024, 1, "solve"),          # <256,4>
