@@ -230,8 +230,8 @@ def other_solver_leg(args, dev, batches, timed, answers, make_solve, P):
     torch.equal of every ans[P,4,4] against the timed run, and that search's own timing + roofline."""
     from houv_amd import solver
     other = not solver.PRUNED
-    if other and args.points > solver.PRUNED_MAX_POINTS:
-        return {"skipped": "the pruned search serves clouds of <= 2048 points (64-bit visit masks)"}
+    if not solver.uses_pruned(args.points, args.points, True):
+        return {"skipped": "both searches run the brute-force kernel at this cloud size (the pruned search serves 513..2048 points)"}
     old, solver.PRUNED = solver.PRUNED, other
     try:
         solve = make_solve()
@@ -532,7 +532,7 @@ def main():
         if not args.no_other_solver and not args.icp:
             timed = [b for b, _ in results]
             leg = other_solver_leg(args, dev, batches, timed, {b: a for b, a in results}, make_solve, P)
-            out["brute_force" if use_pruned else "pruned"] = leg
+            out["brute_force" if args.solver == "pruned" else "pruned"] = leg
             if "value" in leg:
                 leg["ratio_timed_run_over_this"] = out["value"] / leg["value"]
         if not args.no_chamfer_op:

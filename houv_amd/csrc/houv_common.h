@@ -27,7 +27,7 @@ inline bool check_launch(const char* what) {
 // Diagnostic switches (houv_debug_set; tests, A/B scripts and bench.py only -- never the environment).  Results are proven
 // independent of every switch except the two that select an alternative kernel for A/B timing (chamfer_direct, gemm_*).
 //   "solve_predict"   0 normal; 1 always predict direction B (every A-win takes the repair path); 2 rescan everything
-//   "prune_refresh"   pruned mode: every n-th iteration refreshes every remembered nearest neighbour (default 2)
+//   "prune_refresh"   pruned mode: every n-th iteration refreshes every remembered nearest neighbour (default 4)
 //   "prune_cap_slack" pruned walk: lock-step passes run for (mean list length of the wave + this) steps; -1 = fused loop only
 //   "solve_stats"     device address of 4 uint64 counters the fused loop's sweeps add to (0 = off): see SolveArgs::stats
 //   "prune_owner_walk" 1: the pruned search walks its sub-tile lists by owner lanes at every size (A/B against the balanced walk)
@@ -36,7 +36,7 @@ inline bool check_launch(const char* what) {
 //   "gemm_4w" / "gemm_guarded"   houv_gemm_f32: 4-wave workgroups / always the guarded tile fetch
 struct DebugKnobs {
   std::atomic<int> pred_mode{0};
-  std::atomic<int> ws_refresh{2};
+  std::atomic<int> ws_refresh{4};
   std::atomic<int> prune_cap_slack{1};   // pruned walk: lock-step passes capped at the wave's mean list length + this (< 0: off)
   std::atomic<unsigned long long> stats{0ull};
   std::atomic<int> prune_owner_walk{0};  // 1: the pruned search walks its lists by owner lanes at every size (round 2's walk)

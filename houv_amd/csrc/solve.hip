@@ -450,8 +450,11 @@ __device__ __forceinline__ void repair_direction_a(const Smem& sm, const float* 
 // PRUNE: the exact pruned search of houv_sweep.h.  OWN: a lane owns Q/OWN chunks of OWN consecutive points (pt_index);
 // 1 (strided, coalesced loads) everywhere by default -- other values are build-time experiments of the pruned mode
 // (HOUV_PRUNE_OWN), for which <PRUNE=false, OWN> is the brute-force sweep under the same summation order (ws_valid=-1).
+// Waves per SIMD the register budget is set for: 4 (128 VGPRs); 8 (64 VGPRs) where a lane owns one point -- small clouds spend
+// a larger share of an iteration in barrier-separated phases that only OTHER workgroups on the CU can hide (measured +2-3 %
+// up to 256 points; 6 waves per SIMD for two points per lane measured -2 % at 512 points and is not used).
 template <int BLOCK, int Q, int NMET, int PRUNE, int OWN>
-__global__ __launch_bounds__(BLOCK, 4) void solve_kernel(SolveArgs a) {
+__global__ __launch_bounds__(BLOCK, (Q == 1 ? 8 : 4)) void solve_kernel(SolveArgs a) {
   static_assert(PRUNE != 2 || OWN == 1, "the balanced pruned sweep keeps the strided point ownership");
   extern __shared__ __attribute__((aligned(512))) unsigned char smem_raw[];   // 512 B: pruned_sweep's XOR-rotated gathers
   const int N = a.N, M = a.M;
@@ -859,8 +862,9 @@ static int solve_dispatch(const float* src, const float* tgt, int P, int N, int 
     set_error("%s: too many hypotheses", who);
     return 0;
   }
-  // pruned mode refreshes every remembered NN on every 2nd iteration (same-device A/B, profiles/r02_ab_pruned_refresh.txt:
-  // 1 -> 0.988, 2 -> 0.960, 4 -> 0.963, 8 -> 0.990, never -> 1.09 us per hypothesis-iteration; results identical in all).
+  // pruned mode refreshes every remembered NN on every 4th iteration (same-device A/B with the balanced walk,
+  // profiles/r03_ab_refresh.txt: 1 -> 0.697, 2 -> 0.667, 4 -> 0.658, 6 -> 0.657, 8 -> 0.658 us per hypothesis-iteration; round 2's
+  // owner walk, whose steps cost more, preferred 2: profiles/r02_ab_pruned_refresh.txt; results identical in all).
   // pred_mode / ws_refresh / cap_slack / stats are diagnostics set through houv_debug_set(), never through the environment.
   SolveArgs a{src, tgt, P, N, M, K, state, steps_done, n_iters, angle_base, trans_mode, f64_params, k_full, k_view,
               lr, beta1, beta2, eps, loss_scale, out_score, out_loss, out_R, out_T, out_grad, out_cd, nn_ws, ws_valid,

@@ -30,7 +30,7 @@ def _run(argv, monkeypatch):
 
 
 def test_bench_line_contract(monkeypatch):
-    d = _run(["--gpus", "1", "--steps", "2", "--warmup", "1", "--pairs", "8", "--points", "512", "--kernel", "26",
+    d = _run(["--gpus", "1", "--steps", "2", "--warmup", "1", "--pairs", "8", "--points", "768", "--kernel", "26",
               "--iters", "40", "--no-cpu-baseline", "--no-chamfer-op"], monkeypatch)
     for key, typ in (("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int),
                      ("ms_per_step", float), ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str),
@@ -46,7 +46,7 @@ def test_bench_line_contract(monkeypatch):
     # frac = executed flops / peak: flops really executed, so it cannot exceed 1 -- nor the ~0.5 the instruction mix allows
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and 0 < r["frac"] < 0.6
     assert r["frac_executed_flops"] == r["frac"] and "executed fp32 flops" in r["frac_definition"]
-    assert "solve_kernel<256, 2, 4, 1, 1>" in r["kernel"]          # the product default = the pruned search; derived from the launches
+    assert "solve_kernel<256, 3, 4, 2, 1>" in r["kernel"]          # the product default = the pruned search; derived from the launches
     assert "pruned" in d["config"]["solver"]
     assert r["launches"] > 0 and r["kernel_time_share"] <= 1.0
     # traffic comes from a committed PMC pass and is only passed on when that pass profiled THIS library build
@@ -61,17 +61,21 @@ def test_bench_line_contract(monkeypatch):
     b = d["brute_force"]                                              # every timed batch again through the brute-force sweep
     assert b["bit_identical_to_timed_run"] is True and b["batches_compared"] == 2 and b["unit"] == "pairs/s"
     br = b["roofline"]
-    assert "solve_kernel<256, 2, 4, 0, 1>" in br["kernel"] and 0 < br["frac"] < 0.6
+    assert "solve_kernel<256, 3, 4, 0, 1>" in br["kernel"] and 0 < br["frac"] < 0.6
     assert 0 < br["valu_issue_slot_model"]["occupancy_at_sustained_clock"] < 1.1
     assert "pruned_search" not in br
 
 
 def test_bench_brute_solver_flag(monkeypatch):
     """--solver brute times north_star's brute-force formulation; the other leg is then the pruned search."""
-    d = _run(["--gpus", "1", "--steps", "1", "--warmup", "1", "--pairs", "8", "--points", "512", "--kernel", "26",
+    d = _run(["--gpus", "1", "--steps", "1", "--warmup", "1", "--pairs", "8", "--points", "768", "--kernel", "26",
               "--iters", "30", "--no-cpu-baseline", "--no-chamfer-op", "--solver", "brute"], monkeypatch)
-    assert "solve_kernel<256, 2, 4, 0, 1>" in d["roofline"]["kernel"] and d["config"]["solver"].startswith("brute")
-    assert d["pruned"]["bit_identical_to_timed_run"] is True and "4, 1, 1>" in d["pruned"]["roofline"]["kernel"]
+    assert "solve_kernel<256, 3, 4, 0, 1>" in d["roofline"]["kernel"] and d["config"]["solver"].startswith("brute")
+    assert d["pruned"]["bit_identical_to_timed_run"] is True and "4, 2, 1>" in d["pruned"]["roofline"]["kernel"]
+    # up to 512 points both searches are the brute-force kernel: nothing to compare, and the line says so
+    d = _run(["--gpus", "1", "--steps", "1", "--warmup", "1", "--pairs", "8", "--points", "512", "--kernel", "26",
+              "--iters", "20", "--no-cpu-baseline", "--no-chamfer-op"], monkeypatch)
+    assert "solve_kernel<256, 2, 4, 0, 1>" in d["roofline"]["kernel"] and "skipped" in d["brute_force"]
 
 
 def test_bench_one_rank_through_rccl():
