@@ -219,7 +219,8 @@ def kernel_roofline(log, log_all, dt, all_inst_iters, n_retry_launches, stats, p
                                "streams and are not in these sums" % n_retry_launches,
               "kernel_time_share": secs / dt, "hypothesis_iterations_share": inst_iters / max(all_inst_iters, 1)})
     if log_all is not None:
-        # all launches of the process so far (warm-up included) = what `rocprofv3 --kernel-trace --stats` averages over
+        # all launches of this kernel by the process so far (warm-up and the counters' extra stage included) = what
+        # `rocprofv3 --kernel-trace --stats` averages over
         r["launches_incl_warmup"] = len(log_all)
         r["avg_launch_ms_incl_warmup"] = sum(e0.elapsed_time(e1) for e0, e1, *_ in log_all) / max(len(log_all), 1)
     return r
@@ -500,9 +501,12 @@ def main():
     log_base = [e for e in log if e[2] == P * args.kernel]
     stats = None
     if rank == 0:
+        solver.LAUNCH_LOG = []
         stats = solve_stats_pass(lambda s, t: solver.run_stage(
             s, t, solver.houv_init_params(P * args.kernel), args.kernel, min(args.iters, 50), angle_base=0, trans_mode=0,
             use_views=True, f64_params=False, lr=0.01), batches[b_last])
+        log_all = log_all + solver.LAUNCH_LOG          # the profiler sees this launch too (launches_incl_warmup)
+        solver.LAUNCH_LOG = None
     roofline = kernel_roofline(log_base, log_all, dt, all_inst_iters, len(log) - len(log_base), stats, args.points)
     out = {
         "metric": "registration pairs/sec (2048-pt partial pairs)", "value": n_total * args.steps / dt,
