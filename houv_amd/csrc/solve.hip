@@ -450,9 +450,7 @@ __device__ __forceinline__ void repair_direction_a(const Smem& sm, const float* 
 // PRUNE: the exact pruned search of houv_sweep.h.  OWN: a lane owns Q/OWN chunks of OWN consecutive points (pt_index);
 // 1 (strided, coalesced loads) everywhere by default -- other values are build-time experiments of the pruned mode
 // (HOUV_PRUNE_OWN), for which <PRUNE=false, OWN> is the brute-force sweep under the same summation order (ws_valid=-1).
-// Waves per SIMD the register budget is set for: 4 (128 VGPRs); 8 (64 VGPRs) where a lane owns one point -- small clouds spend
-// a larger share of an iteration in barrier-separated phases that only OTHER workgroups on the CU can hide (measured +2-3 %
-// up to 256 points; 6 waves per SIMD for two points per lane measured -2 % at 512 points and is not used).
+// Waves per SIMD the register budget is set for: 4 (128 VGPRs); 8 (64 VGPRs) where a lane owns one point.
 template <int BLOCK, int Q, int NMET, int PRUNE, int OWN>
 __global__ __launch_bounds__(BLOCK, (Q == 1 ? 8 : 4)) void solve_kernel(SolveArgs a) {
   static_assert(PRUNE != 2 || OWN == 1, "the balanced pruned sweep keeps the strided point ownership");
@@ -797,9 +795,8 @@ constexpr int kOwn4 = HOUV_PRUNE_OWN;
 
 // The variant table: which solve_kernel<BLOCK, Q> serves clouds of max(N, M) points -- the SAME (BLOCK, Q) for the brute-force
 // sweep and for the pruned search, so that both sum in the same order and agree bit for bit.  Q = 3 points per lane covers
-// the sizes between the powers of two without idle lanes (768, 1536, 3072).  The pruned search walks its sub-tile lists
-// balanced (PRUNE = 2, pruned_sweep_sorted) where a workgroup has at least 3 blocks of 64 queries per wave to deal out
-// (Q >= 3), by owner lanes (PRUNE = 1) below.  tests/test_host_logic.py enumerates this table and fails when a variant
+// the sizes between the powers of two without idle lanes (768, 1536, 3072).  The pruned search (PRUNE = 2: balanced walk,
+// pruned_sweep_sorted) serves 513..2048 points.  tests/test_host_logic.py enumerates this table and fails when a variant
 // has no size that the GPU tests compare with the CPU oracle.
 extern "C" int houv_solve_variant(int N, int M, int pruned, int* block, int* points_per_lane, int* prune_mode) {
   using namespace houv;
@@ -816,8 +813,12 @@ extern "C" int houv_solve_variant(int N, int M, int pruned, int* block, int* poi
     set_error("houv_solve_iterate: clouds larger than 4096 points do not fit in 160 KiB of LDS (N=%d M=%d)", N, M);
     return 0;
   }
+  // Small clouds: no idle waves (every wave of a workgroup runs the whole epilogue, points or not).  Measured and NOT kept
+  // (profiles/r03_sizes.txt): one wave with 2 points per lane at 65..128 points (+7 %, but it regroups the sums, and the
+  // statistical G14 rung is calibrated on this grouping), one wave with 3-4 points per lane up to 256 points and two waves up to
+  // 512 points (5-6 % SLOWER than 4 waves with 1-2 points per lane).
   int b, q;
-  if (mx <= 64) { b = 64; q = 1; }            // small clouds: no idle waves (every wave runs the whole epilogue, points or not)
+  if (mx <= 64) { b = 64; q = 1; }
   else if (mx <= 128) { b = 128; q = 1; }
   else if (mx <= 256) { b = 256; q = 1; }
   else if (mx <= 512) { b = 256; q = 2; }
@@ -831,7 +832,7 @@ extern "C" int houv_solve_variant(int N, int M, int pruned, int* block, int* poi
   if (points_per_lane) *points_per_lane = q;
   // Up to 512 points the pruned search does not pay (profiles/r03_sizes.txt: 16 sub-tiles or fewer, the bounds, box tests
   // and lists cost more than they save): houv_solve_iterate_pruned then runs the brute-force kernel -- the same result.
-  if (prune_mode) *prune_mode = (!pruned || q < 3) ? 0 : ((b == 512 && q == 4 && g_debug.prune_owner_walk.load()) ? 1 : 2);
+  if (prune_mode) *prune_mode = (!pruned || mx <= 512) ? 0 : ((b == 512 && q == 4 && g_debug.prune_owner_walk.load()) ? 1 : 2);
   return 1;
 }
 
@@ -886,7 +887,7 @@ static int solve_dispatch(const float* src, const float* tgt, int P, int N, int 
   // one instantiation per row of the variant table (houv_solve_variant), x {views, no views}, x {brute force, pruned}
 #define HOUV_GO(B_, Q_)                                                          \
   if (block == B_ && q == Q_) {                                                  \
-    if (mode == 2) return launch<B_, Q_, (Q_ >= 3 ? 2 : 0), 1>(a, use_views, s); \
+    if (mode == 2) return launch<B_, Q_, (B_ >= 256 ? 2 : 0), 1>(a, use_views, s); \
     return launch<B_, Q_, 0, 1>(a, use_views, s);                                \
   }
   if (mx <= 2048) {
