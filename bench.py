@@ -255,7 +255,7 @@ def other_solver_leg(args, dev, batches, timed, answers, make_solve, P):
     return {"solver": "houv_solve_iterate_pruned (exact pruned search)" if other else "houv_solve_iterate (brute-force sweep, north_star's formulation)",
             "value": P * len(timed) / dt, "unit": "pairs/s", "steps": len(timed), "ms_per_step": dt * 1e3 / len(timed),
             "bit_identical_to_timed_run": all(identical), "batches_compared": len(identical),
-            "compared": "ans[P,4,4] of EVERY timed batch, torch.equal against the timed run of the same (Morton-sorted) batch",
+            "compared": "ans[P,4,4] of EVERY timed batch, torch.equal against the timed run of the same (spatially sorted) batch",
             "roofline": kernel_roofline(base, None, dt, all_ii, len(log) - len(base), stats, args.points)}
 
 
@@ -302,7 +302,7 @@ def bench_dcp(args, dev, world, rank):
     from houv_amd.models.houv import Predict_loss
     P = args.pairs
     torch.manual_seed(2021)
-    net = Model(None, pairs_per_chunk=int(os.environ.get("HOUV_DCP_CHUNK", 32))).to(dev)
+    net = Model(None, pairs_per_chunk=int(os.environ.get("HOUV_DCP_CHUNK", 16))).to(dev)
     batches = []
     for b in range(args.steps + args.warmup):
         s, t, _ = synthetic.make_pairs(P, args.points, seed=2021, first_id=(b * world + rank) * P)
@@ -393,10 +393,10 @@ def main():
     batches = []
     for b in range(n_batches):
         s, t, pose = synthetic.make_pairs(P, args.points, seed=2021, first_id=(b * world + rank) * P)
-        # The order of the points of a cloud carries no meaning.  The pruned search sorts both clouds along a Morton curve
+        # The order of the points of a cloud carries no meaning.  The pruned search sorts both clouds into k-d leaves of 32 points
         # (solver.run_stage does it; sorting a sorted cloud is the identity); sorting them here, once, outside the timed
         # region makes the brute-force leg see IDENTICAL inputs, so that the two searches can be compared bit for bit
-        batches.append((solver.morton_sort(s.to(dev)), solver.morton_sort(t.to(dev)), pose.to(dev)))
+        batches.append((solver.spatial_sort(s.to(dev)), solver.spatial_sort(t.to(dev)), pose.to(dev)))
     results = []
 
     from houv_amd.models.houv import predict_model

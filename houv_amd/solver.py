@@ -86,6 +86,48 @@ def morton_sort(cloud):
     return torch.gather(cloud, 1, order.unsqueeze(2).expand(-1, -1, 3)).contiguous()
 
 
+def kd_sort(cloud, leaf=32):
+    """Reorder every cloud [P,N,3] so that consecutive runs of ``leaf`` points -- the kernel's 32-point sub-tiles -- are the leaves
+    of a balanced k-d tree: the point range is halved (at a multiple of ``leaf``) along its longest axis, recursively.  Leaves of a
+    k-d tree have tighter boxes than runs of a Morton curve (whose 32-runs straddle the curve's jumps), so the pruned search visits
+    fewer sub-tiles.  The order is CANONICAL: it starts from the lexicographic (x, y, z) order and only uses stable sorts, so it is
+    a function of the point SET -- sorting a sorted cloud again (or any permutation of it) gives the same order, which is what
+    lets bench.py hand identical clouds to both searches."""
+    P, N, _ = cloud.shape
+    for ax in (2, 1, 0):                                    # lexicographic by (x, y, z): canonical starting order
+        order = torch.argsort(cloud[..., ax], dim=1, stable=True)
+        cloud = torch.gather(cloud, 1, order.unsqueeze(2).expand(-1, -1, 3))
+    segs = [(0, N)]
+    while True:
+        nxt, split = [], False
+        for (a, b) in segs:
+            tiles = -(-(b - a) // leaf)
+            if tiles <= 1:
+                nxt.append((a, b))
+                continue
+            split = True
+            seg = cloud[:, a:b]
+            ext = seg.max(dim=1)[0] - seg.min(dim=1)[0]                          # [P,3]
+            axis = ext.argmax(dim=1)                                             # first maximum wins ties: deterministic
+            key = torch.gather(seg, 2, axis.view(P, 1, 1).expand(-1, b - a, 1))[..., 0]
+            order = torch.argsort(key, dim=1, stable=True)
+            cloud[:, a:b] = torch.gather(seg, 1, order.unsqueeze(2).expand(-1, -1, 3))
+            mid = a + (tiles - tiles // 2) * leaf                                # left half gets the extra tile; a multiple of leaf
+            nxt += [(a, mid), (mid, b)]
+        segs = nxt
+        if not split:
+            break
+    return cloud.contiguous()
+
+
+SPATIAL_SORT = "kd"          # "kd" (balanced k-d leaves, round 3) | "morton" (rounds 1-2)
+
+
+def spatial_sort(cloud):
+    """The point order the pruned search wants (spatially compact 32-point sub-tiles)."""
+    return kd_sort(cloud) if SPATIAL_SORT == "kd" else morton_sort(cloud)
+
+
 FUSED_MAX_POINTS = 4096     # both clouds of a hypothesis live in LDS inside the fused kernel (houv_solve_iterate)
 
 
@@ -180,7 +222,7 @@ def run_stage(src, tgt, params, K, n_iters, *, angle_base, trans_mode, use_views
     pruned = PRUNED if pruned is None else pruned
     nn_ws = None
     if uses_pruned(N, tgt.shape[1], pruned):
-        src, tgt = morton_sort(src), morton_sort(tgt)
+        src, tgt = spatial_sort(src), spatial_sort(tgt)
         nn_ws = ops.solve_workspace(n, N, tgt.shape[1], dev)
     done, out = 0, None
     last_params = None

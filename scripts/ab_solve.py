@@ -8,7 +8,7 @@ from houv_amd import solver, synthetic
 dev = torch.device("cuda:0")
 P, K, N, iters = int(os.environ.get("P", 64)), 64, int(os.environ.get("N", 2048)), int(os.environ.get("ITERS", 20))
 src, tgt, _ = synthetic.make_pairs(P, N, seed=1)
-src, tgt = solver.morton_sort(src.to(dev)), solver.morton_sort(tgt.to(dev))
+src, tgt = solver.spatial_sort(src.to(dev)), solver.spatial_sort(tgt.to(dev))
 p0 = solver.houv_init_params(P * K)
 out = []
 for label, views, pruned in (("brute/views", True, False), ("brute/noviews", False, False), ("pruned/views", True, True), ("pruned/noviews", False, True)):

@@ -5,7 +5,7 @@ from houv_amd import solver, synthetic
 dev = torch.device("cuda:0")
 P, K, N = int(os.environ.get("P", 32)), 64, 2048
 src, tgt, _ = synthetic.make_pairs(P, N, seed=1)
-src, tgt = solver.morton_sort(src.to(dev)), solver.morton_sort(tgt.to(dev))
+src, tgt = solver.spatial_sort(src.to(dev)), solver.spatial_sort(tgt.to(dev))
 p0 = solver.houv_init_params(P * K)
 def timed(fn, n=2):
     fn(); torch.cuda.synchronize(); ts = []

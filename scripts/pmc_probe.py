@@ -9,7 +9,7 @@ dev = torch.device("cuda:0")
 P, K, N, iters = int(os.environ.get("P", 256)), 64, int(os.environ.get("N", 2048)), int(os.environ.get("ITERS", 50))
 launches = int(os.environ.get("LAUNCHES", 3))
 src, tgt, _ = synthetic.make_pairs(P, N, seed=2021)
-src, tgt = solver.morton_sort(src.to(dev)), solver.morton_sort(tgt.to(dev))
+src, tgt = solver.spatial_sort(src.to(dev)), solver.spatial_sort(tgt.to(dev))
 p0 = solver.houv_init_params(P * K)
 which = os.environ.get("SOLVER", "both")
 for name in (("pruned", "brute") if which == "both" else (which,)):

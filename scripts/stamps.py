@@ -11,7 +11,7 @@ src, tgt, _ = synthetic.make_pairs(P, N, seed=1)
 src, tgt = src.to(dev), tgt.to(dev)
 p0 = solver.houv_init_params(P * K)
 solver.PRUNED = bool(int(os.environ.get('PRUNED', '0')))
-src, tgt = solver.morton_sort(src), solver.morton_sort(tgt)
+src, tgt = solver.spatial_sort(src), solver.spatial_sort(tgt)
 lib = _lib.load()
 if os.environ.get("OWNER_WALK") == "1":
     _lib.debug_set("prune_owner_walk", 1)

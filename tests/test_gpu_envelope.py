@@ -68,9 +68,14 @@ def _divergence(a, ref):
 
 
 def _inside_envelope(gpu, env, floor, what):
-    """Bulk quantiles within 3x the envelope's (+ an fp32 rounding floor); decade-threshold exceedance counts within 3x (+3)."""
+    """Bulk quantiles within 3x the envelope's (+ an fp32 rounding floor); decade-threshold exceedance counts within 3x (+3).
+    With fewer than 64 hypotheses (G20 / G21: 26) the 90th percentile IS the third-largest value, i.e. it is set by the two or
+    three hypotheses that happened to diverge first: there the factor is 5 (round 3: three point orders of the same cloud --
+    as given, Morton, k-d leaves -- measured 0.5x / 0.5x / 3.3x the envelope's q90 at one horizon and 0.2-0.9x at the others,
+    scripts/probe_g20.py); the median keeps the factor 3 and the decade counts bound the tail either way."""
     for qq in (0.5, 0.9):
-        assert np.quantile(gpu, qq) <= 3.0 * np.quantile(env, qq) + floor, (what, qq, np.quantile(gpu, qq), np.quantile(env, qq))
+        factor = 5.0 if (qq > 0.5 and len(gpu) < 64) else 3.0
+        assert np.quantile(gpu, qq) <= factor * np.quantile(env, qq) + floor, (what, qq, np.quantile(gpu, qq), np.quantile(env, qq))
     for thr in (1e-5, 1e-4, 1e-3, 1e-2, 1e-1):
         if thr > 10 * floor:
             assert (gpu > thr).sum() <= 3 * (env > thr).sum() + 3, (what, thr, int((gpu > thr).sum()), int((env > thr).sum()))

@@ -353,8 +353,8 @@ def test_pruned_search_is_bit_identical_to_brute_force(dev, N, M, views, f64, tm
     from houv_amd import solver, synthetic
     P, K = 3, 26
     src, tgt, _ = synthetic.make_pairs(P, max(N, M), seed=31)
-    src = solver.morton_sort(src[:, :N].contiguous().to(dev))
-    tgt = solver.morton_sort(tgt[:, :M].contiguous().to(dev))
+    src = solver.spatial_sort(src[:, :N].contiguous().to(dev))
+    tgt = solver.spatial_sort(tgt[:, :M].contiguous().to(dev))
     p0 = solver.houv_init_params(P * K) if not f64 else np.random.default_rng(1).standard_normal((P * K, 8))
     kw = dict(angle_base=1, trans_mode=tm, use_views=views, f64_params=f64, lr=0.1 if f64 else 0.01, want_grad=True,
               want_cd=True)
@@ -383,7 +383,7 @@ def test_gradient_direction_prediction_does_not_change_results(dev, monkeypatch,
     from houv_amd import solver, synthetic
     P, K = 3, 26
     src, tgt, _ = synthetic.make_pairs(P, N, seed=41)
-    src, tgt = solver.morton_sort(src.to(dev)), solver.morton_sort(tgt.to(dev))
+    src, tgt = solver.spatial_sort(src.to(dev)), solver.spatial_sort(tgt.to(dev))
     p0 = solver.houv_init_params(P * K) if not f64 else np.random.default_rng(2).standard_normal((P * K, 8))
     kw = dict(angle_base=0, trans_mode=tm, use_views=views, f64_params=f64, lr=0.1 if f64 else 0.01, want_grad=True,
               want_cd=True, pruned=pruned)
@@ -466,7 +466,7 @@ def test_fused_solve_through_torch_custom_ops(golden, dev):
     from houv_amd import ops, solver
     ops.register_torch_ops()
     g = golden("g5_trajectory.npz")
-    s, t = solver.morton_sort(T(g["src"]).to(dev)), solver.morton_sort(T(g["tgt"]).to(dev))
+    s, t = solver.spatial_sort(T(g["src"]).to(dev)), solver.spatial_sort(T(g["tgt"]).to(dev))
     P, N, K, n = s.shape[0], s.shape[1], 16, 32
     res = {}
     for pruned in (False, True):
