@@ -52,7 +52,7 @@ def solve_twin_init_params(n_inst):
 # The DEFAULT search since round 3 is the exact pruned one (houv_solve_iterate_pruned): on the same clouds it returns the
 # brute-force sweep's result BIT FOR BIT (tests/test_gpu_solve.py::test_pruned_search_is_bit_identical_to_brute_force,
 # bench.py's `brute_force` leg compares every timed batch) at about half the time.  It wants spatially compact
-# 32-point sub-tiles, so run_stage sorts both clouds along a Morton curve first -- point order carries no meaning to
+# 32-point sub-tiles, so run_stage reorders both clouds into k-d leaves of 32 points first (kd_sort) -- point order carries no meaning to
 # the loss; only the fp32 summation order changes with it.  ``houv_amd.solver.PRUNED = False`` or HOUV_SOLVER=brute
 # selects the brute-force sweep (unsorted clouds, the round-1/2 default); clouds above PRUNED_MAX_POINTS points take it
 # in any case.
@@ -86,7 +86,10 @@ def morton_sort(cloud):
     return torch.gather(cloud, 1, order.unsqueeze(2).expand(-1, -1, 3)).contiguous()
 
 
-def kd_sort(cloud, leaf=32):
+KD_RULE = "extent"           # split axis: "extent" = the longest one | "area" = the one whose halves have the smallest projected area
+
+
+def kd_sort(cloud, leaf=32, rule=None):
     """Reorder every cloud [P,N,3] so that consecutive runs of ``leaf`` points -- the kernel's 32-point sub-tiles -- are the leaves
     of a balanced k-d tree: the point range is halved (at a multiple of ``leaf``) along its longest axis, recursively.  Leaves of a
     k-d tree have tighter boxes than runs of a Morton curve (whose 32-runs straddle the curve's jumps), so the pruned search visits
@@ -107,12 +110,32 @@ def kd_sort(cloud, leaf=32):
                 continue
             split = True
             seg = cloud[:, a:b]
-            ext = seg.max(dim=1)[0] - seg.min(dim=1)[0]                          # [P,3]
-            axis = ext.argmax(dim=1)                                             # first maximum wins ties: deterministic
-            key = torch.gather(seg, 2, axis.view(P, 1, 1).expand(-1, b - a, 1))[..., 0]
-            order = torch.argsort(key, dim=1, stable=True)
-            cloud[:, a:b] = torch.gather(seg, 1, order.unsqueeze(2).expand(-1, -1, 3))
             mid = a + (tiles - tiles // 2) * leaf                                # left half gets the extra tile; a multiple of leaf
+            if (rule or KD_RULE) == "area":
+                # the view terms search in the three axis-dropped projections: pick the split whose two halves have the smallest
+                # summed projected box areas (ties: the lowest axis) -- ~5 % fewer sub-tile visits than the longest-axis rule
+                best = None
+                for ax in range(3):
+                    o = torch.argsort(seg[..., ax], dim=1, stable=True)
+                    cand = torch.gather(seg, 1, o.unsqueeze(2).expand(-1, -1, 3))
+
+                    def area(x):
+                        e = x.max(dim=1)[0] - x.min(dim=1)[0]
+                        return e[:, 0] * e[:, 1] + e[:, 1] * e[:, 2] + e[:, 0] * e[:, 2]
+                    cost = area(cand[:, :mid - a]) + area(cand[:, mid - a:])
+                    if best is None:
+                        best, out = cost, cand
+                    else:
+                        take = cost < best
+                        best = torch.where(take, cost, best)
+                        out = torch.where(take.view(P, 1, 1), cand, out)
+                cloud[:, a:b] = out
+            else:
+                ext = seg.max(dim=1)[0] - seg.min(dim=1)[0]                      # [P,3]
+                axis = ext.argmax(dim=1)                                         # first maximum wins ties: deterministic
+                key = torch.gather(seg, 2, axis.view(P, 1, 1).expand(-1, b - a, 1))[..., 0]
+                order = torch.argsort(key, dim=1, stable=True)
+                cloud[:, a:b] = torch.gather(seg, 1, order.unsqueeze(2).expand(-1, -1, 3))
             nxt += [(a, mid), (mid, b)]
         segs = nxt
         if not split:
@@ -123,9 +146,22 @@ def kd_sort(cloud, leaf=32):
 SPATIAL_SORT = "kd"          # "kd" (balanced k-d leaves, round 3) | "morton" (rounds 1-2)
 
 
+_SORTED = {}                 # data_ptr -> (version, shape, device, order) of tensors spatial_sort itself produced
+
+
 def spatial_sort(cloud):
-    """The point order the pruned search wants (spatially compact 32-point sub-tiles)."""
-    return kd_sort(cloud) if SPATIAL_SORT == "kd" else morton_sort(cloud)
+    """The point order the pruned search wants (spatially compact 32-point sub-tiles).  A tensor this function returned is
+    recognised (address, version counter, shape) and handed back as it is: callers that keep their clouds sorted (bench.py,
+    the drivers' batches) do not pay for the sort again in every stage.  A stale match (the address re-used by another tensor
+    of the same shape) is harmless: the pruned search is exact for ANY point order, an unsorted cloud only makes it slower."""
+    mark = (cloud._version, tuple(cloud.shape), cloud.device, SPATIAL_SORT)
+    if cloud.is_contiguous() and _SORTED.get(cloud.data_ptr()) == mark:
+        return cloud
+    out = kd_sort(cloud) if SPATIAL_SORT == "kd" else morton_sort(cloud)
+    if len(_SORTED) > 512:
+        _SORTED.clear()
+    _SORTED[out.data_ptr()] = (out._version, tuple(out.shape), out.device, SPATIAL_SORT)
+    return out
 
 
 FUSED_MAX_POINTS = 4096     # both clouds of a hypothesis live in LDS inside the fused kernel (houv_solve_iterate)

@@ -105,7 +105,7 @@ int houv_solve_iterate(const float* src, const float* tgt, int P, int N, int M, 
 
 /* Opt-in EXACT accelerated form of houv_solve_iterate (same arguments, same search result): every query remembers its nearest neighbour of the previous iteration; the distance to that point is an
  * attained upper bound, and 32-point sub-tiles whose bounding box lies farther than the bound for all metrics are
- * skipped.  Works best on spatially sorted clouds (houv_amd.solver sorts them along a Morton curve).  The search result
+ * skipped.  Works best on spatially sorted clouds (houv_amd.solver reorders them so that runs of 32 points are k-d-tree leaves).  The search result
  * and the summation order are those of houv_solve_iterate: same outputs BIT FOR BIT when given the same clouds.
  *   nn_ws[P*K, 16, ws_stride] int16  workspace, in/out, opaque to the caller: per hypothesis rows [dir*4 + metric] hold the
  *              previous nearest-neighbour index of every point, rows 8..15 are scratch (ws_stride x 16 bytes);

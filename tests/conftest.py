@@ -42,7 +42,7 @@ def golden():
 @pytest.fixture(params=["pruned", "brute"])
 def solver_mode(request, monkeypatch):
     """The reference-golden ladder runs through BOTH searches of the fused loop: the exact pruned one (the product default
-    since round 3, Morton-sorted clouds) and the brute-force sweep (houv_amd.solver.PRUNED = False, clouds as given)."""
+    since round 3, k-d-sorted clouds) and the brute-force sweep (houv_amd.solver.PRUNED = False, clouds as given)."""
     from houv_amd import solver
     monkeypatch.setattr(solver, "PRUNED", request.param == "pruned")
     return request.param
