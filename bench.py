@@ -232,7 +232,7 @@ def other_solver_leg(args, dev, batches, timed, answers, make_solve, P):
     from houv_amd import solver
     other = not solver.PRUNED
     if not solver.uses_pruned(args.points, args.points, True):
-        return {"skipped": "both searches run the brute-force kernel at this cloud size (the pruned search serves 513..2048 points)"}
+        return {"skipped": "both searches run the brute-force kernel at this cloud size (the pruned search serves 257..2048 points)"}
     old, solver.PRUNED = solver.PRUNED, other
     try:
         solve = make_solve()

@@ -63,7 +63,7 @@ extern "C" int houv_debug_set(const char* name, long long value) {
   using namespace houv;
   const struct { const char* name; std::atomic<int>* knob; long long lo, hi; } ints[] = {
       {"solve_predict", &g_debug.pred_mode, 0, 2},   {"prune_refresh", &g_debug.ws_refresh, 0, 1 << 30},
-      {"prune_cap_slack", &g_debug.prune_cap_slack, -1, 64}, {"prune_owner_walk", &g_debug.prune_owner_walk, 0, 1},
+      {"prune_cap_slack", &g_debug.prune_cap_slack, -1, 64}, {"prune_owner_walk", &g_debug.prune_owner_walk, 0, 1}, {"prune_min_points", &g_debug.prune_min_points, 257, 2049},
       {"chamfer_direct", &g_debug.chamfer_direct, 0, 1}, {"chamfer_q", &g_debug.chamfer_q, 1, 8},
       {"gemm_4w", &g_debug.gemm_4w, 0, 1},           {"gemm_guarded", &g_debug.gemm_guarded, 0, 1}};
   if (name && !strcmp(name, "solve_stats")) {

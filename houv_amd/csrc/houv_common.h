@@ -30,6 +30,7 @@ inline bool check_launch(const char* what) {
 //   "prune_refresh"   pruned mode: every n-th iteration refreshes every remembered nearest neighbour (default 4)
 //   "prune_cap_slack" pruned walk: lock-step passes run for (mean list length of the wave + this) steps; -1 = fused loop only
 //   "solve_stats"     device address of 4 uint64 counters the fused loop's sweeps add to (0 = off): see SolveArgs::stats
+//   "prune_min_points" n: the pruned search serves clouds of n..2048 points (default 257; below, the brute-force kernel runs)
 //   "prune_owner_walk" 1: the pruned search walks its sub-tile lists by owner lanes at every size (A/B against the balanced walk)
 //   "chamfer_direct"  1: houv_chamfer_forward runs the direct sweep instead of the filtered one (same bits)
 //   "chamfer_q"       queries per lane cap of the filtered Chamfer kernel (8)
@@ -39,6 +40,7 @@ struct DebugKnobs {
   std::atomic<int> ws_refresh{4};
   std::atomic<int> prune_cap_slack{1};   // pruned walk: lock-step passes capped at the wave's mean list length + this (< 0: off)
   std::atomic<unsigned long long> stats{0ull};
+  std::atomic<int> prune_min_points{257};  // the pruned search serves clouds of at least this many points (>= 257: two points per lane)
   std::atomic<int> prune_owner_walk{0};  // 1: the pruned search walks its lists by owner lanes at every size (round 2's walk)
   std::atomic<int> chamfer_direct{0};
   std::atomic<int> chamfer_q{8};

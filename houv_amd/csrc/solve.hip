@@ -796,7 +796,7 @@ constexpr int kOwn4 = HOUV_PRUNE_OWN;
 // The variant table: which solve_kernel<BLOCK, Q> serves clouds of max(N, M) points -- the SAME (BLOCK, Q) for the brute-force
 // sweep and for the pruned search, so that both sum in the same order and agree bit for bit.  Q = 3 points per lane covers
 // the sizes between the powers of two without idle lanes (768, 1536, 3072).  The pruned search (PRUNE = 2: balanced walk,
-// pruned_sweep_sorted) serves 513..2048 points.  tests/test_host_logic.py enumerates this table and fails when a variant
+// pruned_sweep_sorted) serves 257..2048 points.  tests/test_host_logic.py enumerates this table and fails when a variant
 // has no size that the GPU tests compare with the CPU oracle.
 extern "C" int houv_solve_variant(int N, int M, int pruned, int* block, int* points_per_lane, int* prune_mode) {
   using namespace houv;
@@ -830,9 +830,10 @@ extern "C" int houv_solve_variant(int N, int M, int pruned, int* block, int* poi
   else { b = 1024; q = 4; }
   if (block) *block = b;
   if (points_per_lane) *points_per_lane = q;
-  // Up to 512 points the pruned search does not pay (profiles/r03_sizes.txt: 16 sub-tiles or fewer, the bounds, box tests
-  // and lists cost more than they save): houv_solve_iterate_pruned then runs the brute-force kernel -- the same result.
-  if (prune_mode) *prune_mode = (!pruned || mx <= 512) ? 0 : ((b == 512 && q == 4 && g_debug.prune_owner_walk.load()) ? 1 : 2);
+  // Up to 256 points (8 sub-tiles or fewer, one point per lane) the pruned search is not built: houv_solve_iterate_pruned then runs
+  // the brute-force kernel -- the same result.  With Morton-ordered sub-tiles it did not pay up to 512 points either; with k-d leaves
+  // it does from 257 on (profiles/r03_sizes.txt: 512 points 0.119 -> 0.093 us, 320 points 0.084 -> 0.071).
+  if (prune_mode) *prune_mode = (!pruned || mx <= g_debug.prune_min_points.load() - 1) ? 0 : ((b == 512 && q == 4 && g_debug.prune_owner_walk.load()) ? 1 : 2);
   return 1;
 }
 
@@ -887,7 +888,7 @@ static int solve_dispatch(const float* src, const float* tgt, int P, int N, int 
   // one instantiation per row of the variant table (houv_solve_variant), x {views, no views}, x {brute force, pruned}
 #define HOUV_GO(B_, Q_)                                                          \
   if (block == B_ && q == Q_) {                                                  \
-    if (mode == 2) return launch<B_, Q_, (B_ >= 256 ? 2 : 0), 1>(a, use_views, s); \
+    if (mode == 2) return launch<B_, Q_, ((B_ >= 256 && Q_ >= 2) ? 2 : 0), 1>(a, use_views, s); \
     return launch<B_, Q_, 0, 1>(a, use_views, s);                                \
   }
   if (mx <= 2048) {

@@ -58,8 +58,8 @@ def solve_twin_init_params(n_inst):
 # in any case.
 PRUNED = os.environ.get("HOUV_SOLVER", "pruned").strip().lower() != "brute"
 PRUNED_MAX_POINTS = 2048     # 64 sub-tiles of 32 points = one 64-bit visit mask per query (houv_solve_variant)
-PRUNED_MIN_POINTS = 513      # up to 512 points (16 sub-tiles) the search costs more than it saves: the library itself runs
-                             # the brute-force kernel there (houv_solve_variant reports prune mode 0; profiles/r03_sizes.txt)
+PRUNED_MIN_POINTS = 257      # up to 256 points (8 sub-tiles, one point per lane) the library itself runs the brute-force kernel
+                             # (houv_solve_variant reports prune mode 0); from 257 on the search pays (profiles/r03_sizes.txt)
 
 
 def uses_pruned(N, M, pruned=None):

@@ -4,7 +4,7 @@ test that enumerates the kernel variant table (test_host_logic.py) and fails whe
 ORACLE_CASES: (N, M, angle_base, mode) -- mode "houv" runs solve_kernel<.., NMET=4> (HOUV module: view terms on, fp32 Adam),
 "solve" runs <.., NMET=1> (train_utils.solve twin: no views, float64 leaves).
 PRUNED_CASES: (N, M, views, f64_params, trans_mode) -- the pruned kernels are compared BIT FOR BIT with the brute-force
-kernel of the same variant, which in turn is compared with the oracle above.  Up to 512 points the library serves the
+kernel of the same variant, which in turn is compared with the oracle above.  Up to 256 points the library serves the
 pruned entry point with the brute-force kernel (prune mode 0): those sizes check exactly that."""
 
 ORACLE_CASES = [
@@ -22,7 +22,7 @@ ORACLE_CASES = [
 
 PRUNED_CASES = [
     (200, 200, True, False, 0), (180, 256, False, True, 1),    # <256,1>: the pruned entry point runs the brute-force kernel
-    (400, 400, True, False, 0), (300, 512, False, True, 1),    # <256,2>: likewise
+    (400, 400, True, False, 0), (300, 512, False, True, 1),    # <256,2>
     (700, 700, True, False, 0), (768, 600, False, True, 1),    # <256,3>
     (1000, 1000, True, False, 0), (900, 1024, False, True, 1),  # <256,4>
     (1400, 1400, True, False, 0), (1000, 1300, False, True, 1),  # <512,3>

@@ -72,10 +72,10 @@ def test_bench_brute_solver_flag(monkeypatch):
               "--iters", "30", "--no-cpu-baseline", "--no-chamfer-op", "--solver", "brute"], monkeypatch)
     assert "solve_kernel<256, 3, 4, 0, 1>" in d["roofline"]["kernel"] and d["config"]["solver"].startswith("brute")
     assert d["pruned"]["bit_identical_to_timed_run"] is True and "4, 2, 1>" in d["pruned"]["roofline"]["kernel"]
-    # up to 512 points both searches are the brute-force kernel: nothing to compare, and the line says so
-    d = _run(["--gpus", "1", "--steps", "1", "--warmup", "1", "--pairs", "8", "--points", "512", "--kernel", "26",
+    # up to 256 points both searches are the brute-force kernel: nothing to compare, and the line says so
+    d = _run(["--gpus", "1", "--steps", "1", "--warmup", "1", "--pairs", "8", "--points", "256", "--kernel", "26",
               "--iters", "20", "--no-cpu-baseline", "--no-chamfer-op"], monkeypatch)
-    assert "solve_kernel<256, 2, 4, 0, 1>" in d["roofline"]["kernel"] and "skipped" in d["brute_force"]
+    assert "solve_kernel<256, 1, 4, 0, 1>" in d["roofline"]["kernel"] and "skipped" in d["brute_force"]
 
 
 def test_bench_one_rank_through_rccl():

@@ -156,7 +156,7 @@ def test_every_solve_kernel_variant_is_oracle_compared():
     assert table == {(64, 1), (128, 1), (256, 1), (256, 2), (256, 3), (256, 4), (512, 3), (512, 4), (1024, 3), (1024, 4)}
     assert _lib.solve_variant(2048, 2048) == (512, 4)            # the kernels bench.py times (BASELINE configs[1]) ...
     assert _lib.solve_variant(2048, 2048, pruned=True, with_mode=True) == (512, 4, 2)     # ... the pruned one with the balanced walk
-    assert _lib.solve_variant(2048, 2048, with_mode=True) == (512, 4, 0) and _lib.solve_variant(400, 400, True, True) == (256, 2, 0)
+    assert _lib.solve_variant(2048, 2048, with_mode=True) == (512, 4, 0) and _lib.solve_variant(400, 400, True, True) == (256, 2, 2) and _lib.solve_variant(200, 200, True, True) == (256, 1, 0)
     from houv_amd import solver                                   # the host switch mirrors the library's prune-mode table
     assert all(solver.uses_pruned(n, n, True) == (_lib.solve_variant(n, n, True, True)[2] != 0) for n in range(1, 2049))
     assert not solver.uses_pruned(3000, 100, True)
@@ -168,7 +168,7 @@ def test_every_solve_kernel_variant_is_oracle_compared():
     assert not missing, f"solve_kernel variants never compared with the oracle: {sorted(missing)}"
     # pruned instantiations = the sizes where the library reports a prune mode other than 0
     ptable = {_lib.solve_variant(n, n, pruned=True) for n in range(1, 2049) if _lib.solve_variant(n, n, True, True)[2] != 0}
-    assert ptable == {(256, 3), (256, 4), (512, 3), (512, 4)}
+    assert ptable == {(256, 2), (256, 3), (256, 4), (512, 3), (512, 4)}
     pcovered = {(_lib.solve_variant(N, M, pruned=True), 4 if views else 1) for N, M, views, _, _ in PRUNED_CASES}
     pmissing = {(v, nmet) for v in ptable for nmet in (4, 1)} - pcovered
     assert not pmissing, f"pruned solve_kernel variants never compared with brute force: {sorted(pmissing)}"
