@@ -164,6 +164,15 @@ def spatial_sort(cloud):
     return out
 
 
+def _is_marked_sorted(cloud):
+    return cloud.is_contiguous() and _SORTED.get(cloud.data_ptr()) == (cloud._version, tuple(cloud.shape), cloud.device, SPATIAL_SORT)
+
+
+def _mark_sorted(cloud):
+    """Record that every cloud of this (contiguous) tensor is in spatial_sort order -- e.g. a row subset of a sorted batch."""
+    _SORTED[cloud.data_ptr()] = (cloud._version, tuple(cloud.shape), cloud.device, SPATIAL_SORT)
+
+
 FUSED_MAX_POINTS = 4096     # both clouds of a hypothesis live in LDS inside the fused kernel (houv_solve_iterate)
 
 
@@ -313,7 +322,10 @@ def best_of_k_with_retry(stage_fn, src, tgt):
     best, _ = score.topk(1, dim=1, largest=False, sorted=True)          # NaN hypotheses sort last
     retry = torch.nonzero(best[:, 0] > RETRY_THRESHOLD).reshape(-1)
     if retry.numel() > 0:
-        s_add, t_add = src[retry], tgt[retry]
+        s_add, t_add = src[retry].contiguous(), tgt[retry].contiguous()
+        for sub, whole in ((s_add, src), (t_add, tgt)):        # pairs picked out of a sorted batch are sorted: the three retry
+            if _is_marked_sorted(whole):                        # stages need not sort them again
+                _mark_sorted(sub)
         outs = {}
         if CONCURRENT_RETRIES and src.is_cuda:
             main = torch.cuda.current_stream(src.device)

@@ -6,14 +6,14 @@ import torch
 from houv_amd import _lib, solver, synthetic
 dev = torch.device("cuda:0")
 K = 64
-for N in (512, 448, 384, 320, 768):
+for N in [int(x) for x in os.environ.get("SIZES", "512,448,384,320,768").split(",")]:
     P = 256
     src0, tgt0, _ = synthetic.make_pairs(P, N, seed=1)
     src, tgt = solver.spatial_sort(src0.to(dev)), solver.spatial_sort(tgt0.to(dev))
     p0 = solver.houv_init_params(P * K)
     for views in (True, False):
         out = []
-        for label, minpts, pruned in (("brute", 513, False), ("pruned", 257, True)):
+        for label, minpts, pruned in (("brute", 2049, False), ("pruned", 257, True)):
             _lib.debug_set("prune_min_points", minpts); solver.PRUNED_MIN_POINTS = minpts
             f = lambda: solver.run_stage(src, tgt, p0, K, 100, angle_base=0, trans_mode=0 if views else 1, use_views=views,
                                          f64_params=not views, lr=0.01, pruned=pruned)
