@@ -152,17 +152,18 @@ def kernel_roofline(log, log_all, dt, all_inst_iters, n_retry_launches, stats, p
     pairs_brute = sum(n * it * 2.0 * N * M for _, _, n, it, N, M, *_ in log)          # point pairs of two full sweeps
     views = bool(log[0][6]) if log else True
     flop_pp = EXEC_FLOP_PER_PAIR[views]
-    kinds = sorted({(_lib.solve_variant(N, M, pruned, with_mode=True), 4 if v else 1) for _, _, _, _, N, M, v, _ in log})
+    kinds = sorted({(_lib.solve_variant(N, M, pruned, with_mode=True), 4 if v else 1) for _, _, _, _, N, M, v, *_ in log})
     kname = ", ".join("houv::solve_kernel<%d, %d, %d, %d, 1>" % (b, q, nm, mode) for (b, q, mode), nm in kinds)
     r = {"kernel": kname, "bound": "valu", "unit": "TFLOP/s", "peak": FP32_PEAK_TFLOPS}
     if pruned and stats and stats["pruned_wave_sweeps"]:
         # executed point pairs: every sub-tile a lane asked for = 32 evaluations (+ the brute-force first iteration of a stage)
-        ws = stats["pruned_wave_sweeps"] + stats["brute_wave_sweeps"]
         q = max(kinds[0][0][1], 1)                                          # queries (= sub-tile lists) per lane
         tiles_per_query = stats["asked"] / (stats["pruned_wave_sweeps"] * 64.0 * q)
         steps_per_wave_sweep = stats["steps"] / float(stats["pruned_wave_sweeps"])
         ntile = -(-points // 32)
-        share_pruned = stats["pruned_wave_sweeps"] / float(ws)
+        # the first iteration of a stage has no remembered neighbours and sweeps everything: one iteration of every first launch
+        brute_iters = sum(n for _, _, n, _, _, _, _, _, first in log if first)
+        share_pruned = 1.0 - brute_iters / float(max(inst_iters, 1))
         useful_share = share_pruned * tiles_per_query / ntile + (1.0 - share_pruned)
         pairs_exec = pairs_brute * useful_share
         r["pruned_search"] = {
@@ -175,7 +176,7 @@ def kernel_roofline(log, log_all, dt, all_inst_iters, n_retry_launches, stats, p
     else:
         pairs_exec = pairs_brute
     flops_exec = pairs_exec * flop_pp
-    flops_alg = sum(n * it * (8.0 if v else 2.0) * N * M for _, _, n, it, N, M, v, _ in log) * FLOP_PER_EVAL
+    flops_alg = sum(n * it * (8.0 if v else 2.0) * N * M for _, _, n, it, N, M, v, *_ in log) * FLOP_PER_EVAL
     r["achieved"] = flops_exec / secs / 1e12
     r["frac"] = r["achieved"] / FP32_PEAK_TFLOPS
     r["frac_definition"] = ("executed fp32 flops of the nearest-neighbour evaluations (13 per 4-metric point pair, 8 per single-"

@@ -11,7 +11,7 @@ from . import ops
 RETRY_THRESHOLD = 0.030      # houv.py:156, train_utils.py:494 (strict >)
 ITERS_PER_LAUNCH = 50        # bound single-launch duration; state round-trips through HBM (192 B/hypothesis)
 
-# bench.py sets this to a list to collect (start_event, end_event, hypotheses, iterations, N, M, use_views, pruned) per
+# bench.py sets this to a list to collect (start_event, end_event, hypotheses, iterations, N, M, use_views, pruned, first) per
 # houv_solve_iterate[_pruned] launch: HIP events recorded on the stream the kernel is launched on.
 LAUNCH_LOG = None
 
@@ -290,7 +290,7 @@ def run_stage(src, tgt, params, K, n_iters, *, angle_base, trans_mode, use_views
                                 ws_valid="verify" if pruned == "verify" else done > 0)
         if LAUNCH_LOG is not None:
             ev1.record(torch.cuda.current_stream(dev))
-            LAUNCH_LOG.append((ev0, ev1, n, it, N, tgt.shape[1], bool(use_views), nn_ws is not None))
+            LAUNCH_LOG.append((ev0, ev1, n, it, N, tgt.shape[1], bool(use_views), nn_ws is not None, done == 0))
         done += it
     if want_last_params:
         out["last_params"] = last_params
