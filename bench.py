@@ -160,7 +160,7 @@ def kernel_roofline(log, log_all, dt, all_inst_iters, n_retry_launches, stats, p
         q = max(kinds[0][0][1], 1)                                          # queries (= sub-tile lists) per lane
         tiles_per_query = stats["asked"] / (stats["pruned_wave_sweeps"] * 64.0 * q)
         steps_per_wave_sweep = stats["steps"] / float(stats["pruned_wave_sweeps"])
-        ntile = -(-points // 32)
+        ntile = -(-points // (32 if points <= 2048 else 64))                 # visit-mask bits: sub-tiles, or super-tiles above 2048 points
         # the first iteration of a stage has no remembered neighbours and sweeps everything: one iteration of every first launch
         brute_iters = sum(n for _, _, n, _, _, _, _, _, first in log if first)
         share_pruned = 1.0 - brute_iters / float(max(inst_iters, 1))
@@ -397,7 +397,8 @@ def main():
         # The order of the points of a cloud carries no meaning.  The pruned search sorts both clouds into k-d leaves of 32 points
         # (solver.run_stage does it; sorting a sorted cloud is the identity); sorting them here, once, outside the timed
         # region makes the brute-force leg see IDENTICAL inputs, so that the two searches can be compared bit for bit
-        batches.append((solver.spatial_sort(s.to(dev)), solver.spatial_sort(t.to(dev)), pose.to(dev)))
+        leaf = solver.sort_leaf(args.points, args.points)
+        batches.append((solver.spatial_sort(s.to(dev), leaf), solver.spatial_sort(t.to(dev), leaf), pose.to(dev)))
     results = []
 
     from houv_amd.models.houv import predict_model

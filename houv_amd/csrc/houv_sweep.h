@@ -496,7 +496,9 @@ __device__ __forceinline__ unsigned& w_slot(float4* cloud, int q) { return reint
 
 // wlo / whi: the two LDS clouds (both hold >= count entries); .w of wlo[q] carries the low half of query q's mask and,
 // after the walk, the sub-tile ids of its minima; .w of whi[q] the high half.
-template <int BLOCK, int Q, int NMET>
+// TS = 1 (clouds of 2049..4096 points): the masks are over 64 SUPER-tiles of two sub-tiles each (`boxes`, `ntile` count
+// super-tiles); a visit evaluates both sub-tiles in ascending order, the minima still carry SUB-tile ids (0..127) for the rescans.
+template <int BLOCK, int Q, int NMET, int TS = 0>
 __device__ __forceinline__ void pruned_sweep_sorted(const float4* __restrict__ refs, const float4* __restrict__ boxes, int ntile,
                                                     const float4* __restrict__ qarr, float4* wlo, float4* whi,
                                                     const float (&qx)[Q], const float (&qy)[Q], const float (&qz)[Q],
@@ -562,14 +564,18 @@ __device__ __forceinline__ void pruned_sweep_sorted(const float4* __restrict__ r
     for (int s = 0; s < cap; ++s) {
       t = (mm != 0ull) ? (__ffsll((long long)mm) - 1) : t;
       mm &= mm - 1ull;                                                  // 0 stays 0
-      const unsigned xa = (unsigned)(size_t)(lds_f4)refs + (unsigned)t * (kSub * 16u) + ((unsigned)rot << 4);
-      float tm[1][NMET];
-      gather_tile_min<1, NMET>(xa, cx, cy, cz, tm);
 #pragma unroll
-      for (int m = 0; m < NMET; ++m) {
-        const bool lt = tm[0][m] < cb[m];
-        cb[m] = lt ? tm[0][m] : cb[m];
-        ct[m] = lt ? t : ct[m];
+      for (int h = 0; h < (1 << TS); ++h) {
+        const int ts = (t << TS) | h;                                   // sub-tile
+        const unsigned xa = (unsigned)(size_t)(lds_f4)refs + (unsigned)ts * (kSub * 16u) + ((unsigned)rot << 4);
+        float tm[1][NMET];
+        gather_tile_min<1, NMET>(xa, cx, cy, cz, tm);
+#pragma unroll
+        for (int m = 0; m < NMET; ++m) {
+          const bool lt = tm[0][m] < cb[m];
+          cb[m] = lt ? tm[0][m] : cb[m];
+          ct[m] = lt ? ts : ct[m];
+        }
       }
     }
     if (valid) {
@@ -613,9 +619,12 @@ __device__ __forceinline__ void pruned_sweep_sorted(const float4* __restrict__ r
 // Axis-aligned boxes of the 32-point sub-tiles of a cloud whose points live in this lane's registers (ownership as
 // pt_index): within a chunk a sub-tile spans 32/OWN consecutive lanes x OWN points; an in-lane min/max plus a few
 // xor-shuffles reduce it.  box[2t] = lo, box[2t+1] = hi.
-template <int BLOCK, int Q, int OWN>
+// TS = 1: boxes of SUPER-tiles of 64 points (two sub-tiles; a whole wave when OWN == 1) instead of sub-tiles.
+template <int BLOCK, int Q, int OWN, int TS = 0>
 __device__ __forceinline__ void tile_boxes(const float (&x)[Q], const float (&y)[Q], const float (&z)[Q], int count,
                                            int ntile, float4* __restrict__ box) {
+  constexpr int kTile = kSub << TS;
+  static_assert(kTile / OWN <= 64, "a tile's owners must sit in one wave");
 #pragma unroll
   for (int c = 0; c < Q / OWN; ++c) {
     float lx = INFINITY, ly = INFINITY, lz = INFINITY, hx = -INFINITY, hy = -INFINITY, hz = -INFINITY;
@@ -628,12 +637,12 @@ __device__ __forceinline__ void tile_boxes(const float (&x)[Q], const float (&y)
       }
     }
 #pragma unroll
-    for (int o = 1; o < kSub / OWN; o <<= 1) {
+    for (int o = 1; o < kTile / OWN; o <<= 1) {
       lx = fminf(lx, __shfl_xor(lx, o, 64)); ly = fminf(ly, __shfl_xor(ly, o, 64)); lz = fminf(lz, __shfl_xor(lz, o, 64));
       hx = fmaxf(hx, __shfl_xor(hx, o, 64)); hy = fmaxf(hy, __shfl_xor(hy, o, 64)); hz = fmaxf(hz, __shfl_xor(hz, o, 64));
     }
-    const int t = pt_index<BLOCK, Q, OWN>(c * OWN) / kSub;
-    if (((int)threadIdx.x % (kSub / OWN)) == 0 && t < ntile) {
+    const int t = pt_index<BLOCK, Q, OWN>(c * OWN) / kTile;
+    if (((int)threadIdx.x % (kTile / OWN)) == 0 && t < ntile) {
       box[2 * t] = make_float4(lx, ly, lz, 0.f);
       box[2 * t + 1] = make_float4(hx, hy, hz, 0.f);
     }

@@ -103,19 +103,24 @@ struct Smem {
 };
 
 // prune: 0 brute force, 1 pruned (owner walk), 2 pruned (balanced walk: + staging for block * q queries)
+// PRUNE == 3: the balanced walk over 64-point SUPER-tiles (pairs of sub-tiles) for clouds of 2049..4096 points: the clouds are
+// padded to multiples of 64 points
+__host__ __device__ inline int pad_unit(int prune) { return prune == 3 ? 2 * kSub : kSub; }
+
 __host__ __device__ inline size_t smem_bytes(int N, int M, int block, int prune, int q) {
-  int npad = (N + kSub - 1) / kSub * kSub, mpad = (M + kSub - 1) / kSub * kSub;
-  if (prune == 2) npad = mpad = (npad > mpad ? npad : mpad);   // the balanced walk parks a mask half in EITHER cloud's .w lanes
+  const int pu = pad_unit(prune);
+  int npad = (N + pu - 1) / pu * pu, mpad = (M + pu - 1) / pu * pu;
+  if (prune >= 2) npad = mpad = (npad > mpad ? npad : mpad);   // the balanced walk parks a mask half in EITHER cloud's .w lanes
   const int nw = block / 64;
   const size_t nq = (size_t)block * q;
   return (size_t)(npad + mpad) * 16 + 28 * 8 + kPoseFloats * 4 + 8 * kAccStride * 4 + (size_t)2 * nw * kRedStride * 4 +
          kHistSets * kHistBins * 4 + (8 + nw) * 4 + 64 + (prune ? 2 * 128 * 16 : 0) +
-         (prune == 2 ? nq * 2 + 132 * 4 : 0);
+         (prune >= 2 ? nq * 2 + 132 * 4 : 0);
 }
 
-// nq = BLOCK * Q for the balanced pruned sweep (PRUNE == 2), 0 otherwise
-__device__ inline Smem carve(unsigned char* base, int N, int M, int block, int nq) {
-  int npad = (N + kSub - 1) / kSub * kSub, mpad = (M + kSub - 1) / kSub * kSub;
+// nq = BLOCK * Q for the balanced pruned sweep (PRUNE >= 2), 0 otherwise; pu = pad_unit(PRUNE)
+__device__ inline Smem carve(unsigned char* base, int N, int M, int block, int nq, int pu) {
+  int npad = (N + pu - 1) / pu * pu, mpad = (M + pu - 1) / pu * pu;
   if (nq) npad = mpad = (npad > mpad ? npad : mpad);
   const int nw = block / 64;
   Smem s;
@@ -453,10 +458,12 @@ __device__ __forceinline__ void repair_direction_a(const Smem& sm, const float* 
 // Waves per SIMD the register budget is set for: 4 (128 VGPRs); 8 (64 VGPRs) where a lane owns one point.
 template <int BLOCK, int Q, int NMET, int PRUNE, int OWN>
 __global__ __launch_bounds__(BLOCK, (Q == 1 ? 8 : 4)) void solve_kernel(SolveArgs a) {
-  static_assert(PRUNE != 2 || OWN == 1, "the balanced pruned sweep keeps the strided point ownership");
+  static_assert(PRUNE < 2 || OWN == 1, "the balanced pruned sweep keeps the strided point ownership");
+  constexpr int TS = (PRUNE == 3) ? 1 : 0;                      // visit masks over super-tiles of 32 << TS references
+  constexpr int kPad = kSub << TS;
   extern __shared__ __attribute__((aligned(512))) unsigned char smem_raw[];   // 512 B: pruned_sweep's XOR-rotated gathers
   const int N = a.N, M = a.M;
-  const Smem sm = carve(smem_raw, N, M, BLOCK, PRUNE == 2 ? BLOCK * Q : 0);
+  const Smem sm = carve(smem_raw, N, M, BLOCK, PRUNE >= 2 ? BLOCK * Q : 0, kPad);
   const int tid = threadIdx.x;
   const int ninst = a.P * a.K;
   // XCD-aware placement: workgroups b and b+8 share an XCD (and its L2), so give each XCD a contiguous
@@ -466,14 +473,14 @@ __global__ __launch_bounds__(BLOCK, (Q == 1 ? 8 : 4)) void solve_kernel(SolveArg
   const int pair = inst / a.K;
   const float* __restrict__ src = a.src + (size_t)pair * N * 3;
   const float* __restrict__ tgt = a.tgt + (size_t)pair * M * 3;
-  const int npad = (N + kSub - 1) / kSub * kSub, mpad = (M + kSub - 1) / kSub * kSub;
+  const int npad = (N + kPad - 1) / kPad * kPad, mpad = (M + kPad - 1) / kPad * kPad;
   const float4 pad4 = make_float4(INFINITY, INFINITY, INFINITY, 0.f);   // padding references never win
 
   for (int j = tid; j < mpad; j += BLOCK) sm.tgt[j] = (j < M) ? make_float4(tgt[j * 3], tgt[j * 3 + 1], tgt[j * 3 + 2], 0.f) : pad4;
   for (int j = N + tid; j < npad; j += BLOCK) sm.mov[j] = pad4;
   if (tid < 24) sm.state[tid] = a.state[(size_t)inst * 24 + tid];
   for (int j = tid; j < kHistBins; j += BLOCK) sm.hist[j] = 0u;   // radix-select histogram set 0 (select_smallest rotates)
-  if constexpr (PRUNE == 2) {
+  if constexpr (PRUNE >= 2) {
     if (tid < 132) sm.st.hist[tid] = 0;                           // list-length bins of the balanced pruned sweep
   }
   int hrot = 0;
@@ -493,7 +500,7 @@ __global__ __launch_bounds__(BLOCK, (Q == 1 ? 8 : 4)) void solve_kernel(SolveArg
       const float4 v = (i < M) ? sm.tgt[i] : make_float4(0.f, 0.f, 0.f, 0.f);
       tx0[k] = v.x; ty0[k] = v.y; tz0[k] = v.z;
     }
-    tile_boxes<BLOCK, Q, OWN>(tx0, ty0, tz0, M, mpad / kSub, sm.tbox);   // the target is static: boxes once per launch
+    tile_boxes<BLOCK, Q, OWN, TS>(tx0, ty0, tz0, M, mpad / kPad, sm.tbox);   // the target is static: boxes once per launch
   }
   // Adam's step-dependent scalars (two double pow()) are computed off the critical path: by thread kAdamTid (another wave,
   // hence another SIMD, when the workgroup has one) one iteration ahead, into the slot of the step's parity.
@@ -567,12 +574,12 @@ __global__ __launch_bounds__(BLOCK, (Q == 1 ? 8 : 4)) void solve_kernel(SolveArg
       // ---- sweep A: moved -> target ----
       bool pruned_now = false;
       if constexpr (PRUNE) {
-        tile_boxes<BLOCK, Q, OWN>(mx, my, mz, N, npad / kSub, sm.mbox);   // read by sweep B after the next barriers
+        tile_boxes<BLOCK, Q, OWN, TS>(mx, my, mz, N, npad / kPad, sm.mbox);   // read by sweep B after the next barriers
         pruned_now = (a.ws_valid != 0) || (it > 0);
       }
       if (pruned_now) {
-        if constexpr (PRUNE == 2) {
-          pruned_sweep_sorted<BLOCK, Q, NMET>(sm.tgt, sm.tbox, mpad / kSub, sm.mov, sm.tgt, sm.mov, mx, my, mz, ws_a, a.ws_stride, N,
+        if constexpr (PRUNE >= 2) {
+          pruned_sweep_sorted<BLOCK, Q, NMET, TS>(sm.tgt, sm.tbox, mpad / kPad, sm.mov, sm.tgt, sm.mov, mx, my, mz, ws_a, a.ws_stride, N,
                                               rot, sm.st, ws_res, best, btile, a.stats);
         } else if constexpr (PRUNE == 1) {
           pruned_sweep<BLOCK, Q, NMET, OWN>(sm.tgt, sm.tbox, mpad / kSub, mx, my, mz, ws_a, a.ws_stride, N, rot, best, btile, a.stats, a.cap_slack);
@@ -606,8 +613,8 @@ __global__ __launch_bounds__(BLOCK, (Q == 1 ? 8 : 4)) void solve_kernel(SolveArg
       }
       const bool pruned_now = (PRUNE != 0) && ((a.ws_valid != 0) || (it > 0));
       if (pruned_now) {
-        if constexpr (PRUNE == 2) {
-          pruned_sweep_sorted<BLOCK, Q, NMET>(sm.mov, sm.mbox, npad / kSub, sm.tgt, sm.tgt, sm.mov, tx, ty, tz, ws_b, a.ws_stride, M,
+        if constexpr (PRUNE >= 2) {
+          pruned_sweep_sorted<BLOCK, Q, NMET, TS>(sm.mov, sm.mbox, npad / kPad, sm.tgt, sm.tgt, sm.mov, tx, ty, tz, ws_b, a.ws_stride, M,
                                               rot, sm.st, ws_res, best, btile, a.stats);
         } else if constexpr (PRUNE == 1) {
           pruned_sweep<BLOCK, Q, NMET, OWN>(sm.mov, sm.mbox, npad / kSub, tx, ty, tz, ws_b, a.ws_stride, M, rot, best, btile, a.stats, a.cap_slack);
@@ -795,18 +802,15 @@ constexpr int kOwn4 = HOUV_PRUNE_OWN;
 
 // The variant table: which solve_kernel<BLOCK, Q> serves clouds of max(N, M) points -- the SAME (BLOCK, Q) for the brute-force
 // sweep and for the pruned search, so that both sum in the same order and agree bit for bit.  Q = 3 points per lane covers
-// the sizes between the powers of two without idle lanes (768, 1536, 3072).  The pruned search (PRUNE = 2: balanced walk,
-// pruned_sweep_sorted) serves 257..2048 points.  tests/test_host_logic.py enumerates this table and fails when a variant
+// the sizes between the powers of two without idle lanes (768, 1536, 3072).  The pruned search (balanced walk,
+// pruned_sweep_sorted) serves 257..2048 points with one visit-mask bit per 32-point sub-tile (PRUNE = 2) and 2049..4096 points with
+// one bit per 64-point super-tile (PRUNE = 3; one 1024-thread workgroup per CU there, like the brute-force kernel).  tests/test_host_logic.py enumerates this table and fails when a variant
 // has no size that the GPU tests compare with the CPU oracle.
 extern "C" int houv_solve_variant(int N, int M, int pruned, int* block, int* points_per_lane, int* prune_mode) {
   using namespace houv;
   const int mx = N > M ? N : M;
   if (N <= 0 || M <= 0) {
     set_error("houv_solve_variant: bad cloud sizes N=%d M=%d", N, M);
-    return 0;
-  }
-  if (pruned && mx > 2048) {
-    set_error("houv_solve_iterate_pruned: clouds of <= 2048 points only (64 sub-tiles per 64-bit visit mask), got N=%d M=%d", N, M);
     return 0;
   }
   if (mx > 4096) {
@@ -833,7 +837,8 @@ extern "C" int houv_solve_variant(int N, int M, int pruned, int* block, int* poi
   // Up to 256 points (8 sub-tiles or fewer, one point per lane) the pruned search is not built: houv_solve_iterate_pruned then runs
   // the brute-force kernel -- the same result.  With Morton-ordered sub-tiles it did not pay up to 512 points either; with k-d leaves
   // it does from 257 on (profiles/r03_sizes.txt: 512 points 0.119 -> 0.093 us, 320 points 0.084 -> 0.071).
-  if (prune_mode) *prune_mode = (!pruned || mx <= g_debug.prune_min_points.load() - 1) ? 0 : ((b == 512 && q == 4 && g_debug.prune_owner_walk.load()) ? 1 : 2);
+  if (prune_mode) *prune_mode = (!pruned || mx <= g_debug.prune_min_points.load() - 1) ? 0 : (mx > 2048) ? 3 :
+                               ((b == 512 && q == 4 && g_debug.prune_owner_walk.load()) ? 1 : 2);
   return 1;
 }
 
@@ -896,8 +901,8 @@ static int solve_dispatch(const float* src, const float* tgt, int P, int N, int 
     HOUV_GO(64, 1) HOUV_GO(128, 1) HOUV_GO(256, 1) HOUV_GO(256, 2) HOUV_GO(256, 3) HOUV_GO(256, 4)
     HOUV_GO(512, 3) HOUV_GO(512, 4)
   } else {
-    if (block == 1024 && q == 3) return launch<1024, 3, 0, 1>(a, use_views, s);
-    if (block == 1024 && q == 4) return launch<1024, 4, 0, 1>(a, use_views, s);
+    if (block == 1024 && q == 3) return mode == 3 ? launch<1024, 3, 3, 1>(a, use_views, s) : launch<1024, 3, 0, 1>(a, use_views, s);
+    if (block == 1024 && q == 4) return mode == 3 ? launch<1024, 4, 3, 1>(a, use_views, s) : launch<1024, 4, 0, 1>(a, use_views, s);
   }
 #undef HOUV_GO
   set_error("%s: no kernel variant <%d,%d>", who, block, q);

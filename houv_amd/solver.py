@@ -54,10 +54,9 @@ def solve_twin_init_params(n_inst):
 # bench.py's `brute_force` leg compares every timed batch) at about half the time.  It wants spatially compact
 # 32-point sub-tiles, so run_stage reorders both clouds into k-d leaves of 32 points first (kd_sort) -- point order carries no meaning to
 # the loss; only the fp32 summation order changes with it.  ``houv_amd.solver.PRUNED = False`` or HOUV_SOLVER=brute
-# selects the brute-force sweep (unsorted clouds, the round-1/2 default); clouds above PRUNED_MAX_POINTS points take it
-# in any case.
+# selects the brute-force sweep (unsorted clouds, the round-1/2 default); clouds of up to 256 points take it in any case.
 PRUNED = os.environ.get("HOUV_SOLVER", "pruned").strip().lower() != "brute"
-PRUNED_MAX_POINTS = 2048     # 64 sub-tiles of 32 points = one 64-bit visit mask per query (houv_solve_variant)
+PRUNED_MAX_POINTS = 4096     # the fused kernel's limit; above 2048 points a visit-mask bit covers a 64-point super-tile
 PRUNED_MIN_POINTS = 257      # up to 256 points (8 sub-tiles, one point per lane) the library itself runs the brute-force kernel
                              # (houv_solve_variant reports prune mode 0); from 257 on the search pays (profiles/r03_sizes.txt)
 
@@ -149,28 +148,36 @@ SPATIAL_SORT = "kd"          # "kd" (balanced k-d leaves, round 3) | "morton" (r
 _SORTED = {}                 # data_ptr -> (version, shape, device, order) of tensors spatial_sort itself produced
 
 
-def spatial_sort(cloud):
-    """The point order the pruned search wants (spatially compact 32-point sub-tiles).  A tensor this function returned is
+def spatial_sort(cloud, leaf=32):
+    """The point order the pruned search wants (spatially compact 32-point sub-tiles; ``leaf`` = 64 for clouds of more than 2048
+    points, whose visit masks are over 64-point super-tiles).  A tensor this function returned is
     recognised (address, version counter, shape) and handed back as it is: callers that keep their clouds sorted (bench.py,
     the drivers' batches) do not pay for the sort again in every stage.  A stale match (the address re-used by another tensor
     of the same shape) is harmless: the pruned search is exact for ANY point order, an unsorted cloud only makes it slower."""
-    mark = (cloud._version, tuple(cloud.shape), cloud.device, SPATIAL_SORT)
+    mark = (cloud._version, tuple(cloud.shape), cloud.device, SPATIAL_SORT, leaf)
     if cloud.is_contiguous() and _SORTED.get(cloud.data_ptr()) == mark:
         return cloud
-    out = kd_sort(cloud) if SPATIAL_SORT == "kd" else morton_sort(cloud)
+    out = kd_sort(cloud, leaf) if SPATIAL_SORT == "kd" else morton_sort(cloud)
     if len(_SORTED) > 512:
         _SORTED.clear()
-    _SORTED[out.data_ptr()] = (out._version, tuple(out.shape), out.device, SPATIAL_SORT)
+    _SORTED[out.data_ptr()] = (out._version, tuple(out.shape), out.device, SPATIAL_SORT, leaf)
     return out
 
 
-def _is_marked_sorted(cloud):
-    return cloud.is_contiguous() and _SORTED.get(cloud.data_ptr()) == (cloud._version, tuple(cloud.shape), cloud.device, SPATIAL_SORT)
+def sort_leaf(N, M):
+    """Leaf size of the spatial sort for clouds of N and M points: the pruned search's visit-mask granularity."""
+    return 32 if max(N, M) <= 2048 else 64
 
 
-def _mark_sorted(cloud):
+def _sorted_leaf(cloud):
+    """Leaf size a (contiguous) tensor was spatially sorted with, or None when it is not known to be sorted."""
+    m = _SORTED.get(cloud.data_ptr()) if cloud.is_contiguous() else None
+    return m[4] if m is not None and m[:4] == (cloud._version, tuple(cloud.shape), cloud.device, SPATIAL_SORT) else None
+
+
+def _mark_sorted(cloud, leaf):
     """Record that every cloud of this (contiguous) tensor is in spatial_sort order -- e.g. a row subset of a sorted batch."""
-    _SORTED[cloud.data_ptr()] = (cloud._version, tuple(cloud.shape), cloud.device, SPATIAL_SORT)
+    _SORTED[cloud.data_ptr()] = (cloud._version, tuple(cloud.shape), cloud.device, SPATIAL_SORT, leaf)
 
 
 FUSED_MAX_POINTS = 4096     # both clouds of a hypothesis live in LDS inside the fused kernel (houv_solve_iterate)
@@ -267,7 +274,8 @@ def run_stage(src, tgt, params, K, n_iters, *, angle_base, trans_mode, use_views
     pruned = PRUNED if pruned is None else pruned
     nn_ws = None
     if uses_pruned(N, tgt.shape[1], pruned):
-        src, tgt = spatial_sort(src), spatial_sort(tgt)
+        leaf = sort_leaf(N, tgt.shape[1])
+        src, tgt = spatial_sort(src, leaf), spatial_sort(tgt, leaf)
         nn_ws = ops.solve_workspace(n, N, tgt.shape[1], dev)
     done, out = 0, None
     last_params = None
@@ -324,8 +332,9 @@ def best_of_k_with_retry(stage_fn, src, tgt):
     if retry.numel() > 0:
         s_add, t_add = src[retry].contiguous(), tgt[retry].contiguous()
         for sub, whole in ((s_add, src), (t_add, tgt)):        # pairs picked out of a sorted batch are sorted: the three retry
-            if _is_marked_sorted(whole):                        # stages need not sort them again
-                _mark_sorted(sub)
+            leaf = _sorted_leaf(whole)                          # stages need not sort them again
+            if leaf is not None:
+                _mark_sorted(sub, leaf)
         outs = {}
         if CONCURRENT_RETRIES and src.is_cuda:
             main = torch.cuda.current_stream(src.device)

@@ -113,7 +113,8 @@ int houv_solve_iterate(const float* src, const float* tgt, int P, int N, int M, 
  *   ws_valid   0: nn_ws holds nothing yet (the first iteration of this call runs the brute-force sweep)
  *              1: nn_ws was left by the previous call on the same hypotheses (chunked launches)
  *             -1: verification mode: every iteration runs the brute-force sweep (nn_ws is not used)
- * Limits: N, M <= 2048 (64 sub-tiles per cloud). */
+ * Limits: as houv_solve_iterate (N, M <= 4096).  Up to 256 points the brute-force kernel runs (nothing to prune); up to 2048 points
+ * a visit mask has one bit per 32-point sub-tile, above one bit per pair of sub-tiles. */
 int houv_solve_iterate_pruned(const float* src, const float* tgt, int P, int N, int M, int K,
                               double* state, int steps_done, int n_iters,
                               int angle_base, int trans_mode, int use_views, int f64_params,
@@ -125,9 +126,10 @@ int houv_solve_iterate_pruned(const float* src, const float* tgt, int P, int N, 
 
 /* Which kernel variant the two entry points above launch for clouds of N and M points (host-only query, no GPU work):
  * *block = threads per workgroup (256 / 512 / 1024), *points_per_lane = query points a lane owns (1..4), *prune_mode =
- * 0 brute-force sweep, 1 pruned search walked by the owning lanes, 2 pruned search with the balanced (sorted-block) walk --
+ * 0 brute-force sweep, 1 pruned search walked by the owning lanes, 2 / 3 pruned search with the balanced (sorted-block) walk over
+ * 32-point sub-tiles / 64-point super-tiles --
  * the template arguments of houv::solve_kernel<block, points_per_lane, metrics, prune_mode, 1>.  Any out pointer may be NULL.
- * Returns 0 with houv_last_error() set when no variant serves the size (max(N,M) > 4096; pruned != 0: max(N,M) > 2048).
+ * Returns 0 with houv_last_error() set when no variant serves the size (max(N,M) > 4096).
  * No counterpart in the reference (its kernel has one fixed launch shape, chamfer3D.cu:142-143); exported so that
  * the test-suite can prove that every variant is compared with the CPU oracle. */
 int houv_solve_variant(int N, int M, int pruned, int* block, int* points_per_lane, int* prune_mode);

@@ -27,6 +27,8 @@ PRUNED_CASES = [
     (1000, 1000, True, False, 0), (900, 1024, False, True, 1),  # <256,4>
     (1400, 1400, True, False, 0), (1000, 1300, False, True, 1),  # <512,3>
     (2048, 2048, True, False, 0), (2048, 1700, False, True, 1),  # <512,4>, balanced walk
+    (2500, 2500, True, False, 0), (3000, 2200, False, True, 1),  # <1024,3>, balanced walk over 64-point super-tiles (PRUNE = 3)
+    (4096, 4096, True, False, 0), (3500, 4000, False, True, 1),  # <1024,4>
 ]
 
 

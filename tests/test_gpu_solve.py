@@ -353,8 +353,8 @@ def test_pruned_search_is_bit_identical_to_brute_force(dev, N, M, views, f64, tm
     from houv_amd import solver, synthetic
     P, K = 3, 26
     src, tgt, _ = synthetic.make_pairs(P, max(N, M), seed=31)
-    src = solver.spatial_sort(src[:, :N].contiguous().to(dev))
-    tgt = solver.spatial_sort(tgt[:, :M].contiguous().to(dev))
+    src = solver.spatial_sort(src[:, :N].contiguous().to(dev), solver.sort_leaf(N, M))
+    tgt = solver.spatial_sort(tgt[:, :M].contiguous().to(dev), solver.sort_leaf(N, M))
     p0 = solver.houv_init_params(P * K) if not f64 else np.random.default_rng(1).standard_normal((P * K, 8))
     kw = dict(angle_base=1, trans_mode=tm, use_views=views, f64_params=f64, lr=0.1 if f64 else 0.01, want_grad=True,
               want_cd=True)

@@ -158,21 +158,22 @@ def test_every_solve_kernel_variant_is_oracle_compared():
     assert _lib.solve_variant(2048, 2048, pruned=True, with_mode=True) == (512, 4, 2)     # ... the pruned one with the balanced walk
     assert _lib.solve_variant(2048, 2048, with_mode=True) == (512, 4, 0) and _lib.solve_variant(400, 400, True, True) == (256, 2, 2) and _lib.solve_variant(200, 200, True, True) == (256, 1, 0)
     from houv_amd import solver                                   # the host switch mirrors the library's prune-mode table
-    assert all(solver.uses_pruned(n, n, True) == (_lib.solve_variant(n, n, True, True)[2] != 0) for n in range(1, 2049))
-    assert not solver.uses_pruned(3000, 100, True)
+    assert all(solver.uses_pruned(n, n, True) == (_lib.solve_variant(n, n, True, True)[2] != 0) for n in range(1, 4097))
+    assert solver.uses_pruned(3000, 100, True) and not solver.uses_pruned(5000, 100, True)
     # brute force and pruned search use the SAME (block, points per lane) at every size: same summation order, same bits
-    assert all(_lib.solve_variant(n, n) == _lib.solve_variant(n, n, pruned=True) for n in range(1, 2049))
+    assert all(_lib.solve_variant(n, n) == _lib.solve_variant(n, n, pruned=True) for n in range(1, 4097))
     assert _lib.solve_variant(100, 3000) == (1024, 3)            # the larger cloud decides
     covered = {(_lib.solve_variant(N, M), 4 if mode == "houv" else 1) for N, M, _, mode in ORACLE_CASES}
     missing = {(v, nmet) for v in table for nmet in (4, 1)} - covered
     assert not missing, f"solve_kernel variants never compared with the oracle: {sorted(missing)}"
     # pruned instantiations = the sizes where the library reports a prune mode other than 0
-    ptable = {_lib.solve_variant(n, n, pruned=True) for n in range(1, 2049) if _lib.solve_variant(n, n, True, True)[2] != 0}
-    assert ptable == {(256, 2), (256, 3), (256, 4), (512, 3), (512, 4)}
+    ptable = {_lib.solve_variant(n, n, pruned=True) for n in range(1, 4097) if _lib.solve_variant(n, n, True, True)[2] != 0}
+    assert ptable == {(256, 2), (256, 3), (256, 4), (512, 3), (512, 4), (1024, 3), (1024, 4)}
+    assert _lib.solve_variant(4096, 4096, True, True) == (1024, 4, 3) and _lib.solve_variant(2049, 100, True, True) == (1024, 3, 3)
     pcovered = {(_lib.solve_variant(N, M, pruned=True), 4 if views else 1) for N, M, views, _, _ in PRUNED_CASES}
     pmissing = {(v, nmet) for v in ptable for nmet in (4, 1)} - pcovered
     assert not pmissing, f"pruned solve_kernel variants never compared with brute force: {sorted(pmissing)}"
-    for bad in ((4097, 10, False), (10, 2049, True), (0, 5, False)):
+    for bad in ((4097, 10, False), (10, 4097, True), (0, 5, False)):
         with pytest.raises(_lib.HouvHipError):
             _lib.solve_variant(*bad)
 
