@@ -10,11 +10,15 @@ resident in HBM.  N=1 workload = BASELINE.json configs[1]: 2048x2048-point pairs
 solves its own batch of the same size (weak scaling; pairs are independent, no data-path collective) and the ranks
 exchange the per-pair (R,t) of all timed steps with ONE RCCL all-gather inside the timed region.  Rank 0 prints one JSON line.
 
-Extra objects on the line:
-  roofline      the dominant kernel (houv::solve_kernel, brute-force sweep), timed live with HIP events on its launch stream;
-                VALU-issue bound: `frac` is the share of the chip's VALU issue slots the two sweeps occupy
-  pruned        the same batches through the opt-in EXACT pruned search (houv_solve_iterate_pruned): pairs/s, us per
-                hypothesis-iteration, and whether every transform came out bit-identical to the brute-force run
+`value` = the DEFAULT product path: the exact pruned nearest-neighbour search (houv_solve_iterate_pruned; --solver brute times the
+brute-force sweep instead).  Extra objects on the line:
+  roofline      the dominant kernel of the timed run (houv::solve_kernel<512, 4, 4, 2, 1>), timed live with HIP events on its launch
+                stream; `frac` = EXECUTED fp32 flops of the nearest-neighbour evaluations / 157.3 TFLOP/s (see `frac_definition`);
+                `pruned_search` = what the search visited; `sustained_clock_ghz` = measured inside the kernel; `traffic` and the
+                `valu_*` figures = the committed PMC pass, printed only when it profiled the loaded library build
+  brute_force   EVERY timed batch again through the brute-force sweep (houv_solve_iterate): pairs/s, whether every transform came out
+                bit-identical to the timed run, and that kernel's own roofline (+ the VALU issue-slot model)
+  ranks         N > 1 (or --force-process-group): per-rank seconds, retried pairs, gather time, load balance
   chamfer_op    the stand-alone Chamfer op at the same cloud size (BASELINE metric's "Chamfer HBM GB/s" half)
   cpu_baseline  the CPU oracle (oracle/houv_ref_cpu.py, the reference's PyTorch-CPU formulation) on a bounded sample
 """

@@ -178,7 +178,8 @@ __device__ __forceinline__ float4 recover_nn(const float4* __restrict__ rp, floa
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// EXACT pruned sweep (opt-in, houv_solve_iterate_pruned).  References are grouped in the same 32-point sub-tiles as
+// EXACT pruned sweep (houv_solve_iterate_pruned; this first form, walked by the OWNING lanes, was round 2's and is kept for A/B --
+// the product runs pruned_sweep_sorted further down).  References are grouped in the same 32-point sub-tiles as
 // the brute-force sweep; every sub-tile carries an axis-aligned bounding box.  For every query and metric m the
 // distance to the point that was its NN in the previous iteration is an upper bound ub[m] that is attained; a sub-tile
 // whose box is farther from the query than ub[m] for every metric cannot contain any of its NNs -- nor a point tying

@@ -19,7 +19,11 @@
 //     straight into the 13 sums the parameter gradient needs (sum sqrt d, sum G, sum G p^T);
 //   * top-k (k = N/2 for the full metric) = exact 4-pass 8-bit radix select on the fp32 bit patterns
 //     of the register-resident distances, LDS histogram;
-//   * the un-moved source point needed for sum G p^T in the target->moved direction is R^T(p' - T).
+//   * the un-moved source point needed for sum G p^T in the target->moved direction is R^T(p' - T);
+//   * PRUNE = 0 is that brute-force sweep (north_star's formulation).  PRUNE = 2 / 3 -- the product default for clouds of
+//     257..2048 / 2049..4096 points -- replace the two sweeps by the EXACT pruned search of houv_sweep.h (remembered-NN
+//     bounds + boxes of k-d-leaf sub-tiles + a balanced, sorted-block walk): same (minimum, sub-tile) per query and metric,
+//     hence the same bits everywhere downstream, for ~1/8 of the point pairs.
 #include <stddef.h>
 #include <stdlib.h>
 

@@ -103,7 +103,8 @@ int houv_solve_iterate(const float* src, const float* tgt, int P, int N, int M, 
                        float* out_score, float* out_loss, float* out_R, float* out_T,
                        float* out_grad, float* out_cd, void* stream);
 
-/* Opt-in EXACT accelerated form of houv_solve_iterate (same arguments, same search result): every query remembers its nearest neighbour of the previous iteration; the distance to that point is an
+/* EXACT accelerated form of houv_solve_iterate (same arguments, same search result; what houv_amd.solver runs by default): every
+ * query remembers its nearest neighbour of an earlier iteration; the distance to that point is an
  * attained upper bound, and 32-point sub-tiles whose bounding box lies farther than the bound for all metrics are
  * skipped.  Works best on spatially sorted clouds (houv_amd.solver reorders them so that runs of 32 points are k-d-tree leaves).  The search result
  * and the summation order are those of houv_solve_iterate: same outputs BIT FOR BIT when given the same clouds.

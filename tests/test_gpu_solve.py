@@ -346,7 +346,7 @@ def test_solve_twin_end_to_end_vs_oracle(golden, dev, solver_mode):
 
 @pytest.mark.parametrize("N,M,views,f64,tm", PRUNED_CASES)
 def test_pruned_search_is_bit_identical_to_brute_force(dev, N, M, views, f64, tm):
-    """The opt-in pruned search (previous-NN upper bound + sub-tile bounding boxes) must reproduce the brute-force
+    """The pruned search (previous-NN upper bound + sub-tile bounding boxes; the default since round 3) must reproduce the brute-force
     kernel BIT FOR BIT on the same clouds: scores, losses, poses, gradients, the 8 Chamfer terms and the optimiser state,
     across chunked launches (workspace carried over) and bases -- against houv_solve_iterate itself and against the
     pruned entry point's verification mode (ws_valid=-1, pruning switched off)."""
