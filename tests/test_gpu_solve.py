@@ -1,10 +1,14 @@
 """GPU parity of the fused HOUV loop (houv_solve_iterate) and the host mirrors around it, as a ladder
 (SURVEY.md section 7 "chaotic trajectories"): per-op -> single step -> short horizon -> end-to-end."""
+import os
+import sys
+
 import numpy as np
 import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 from oracle import houv_ref_cpu as orc  # noqa: E402
 from solve_cases import ORACLE_CASES, PRUNED_CASES, oracle_batch  # noqa: E402
@@ -500,3 +504,13 @@ def test_fused_solve_through_torch_custom_ops(golden, dev):
     Ti, fit, rmse, its = torch.ops.houv.icp_refine(s, t, None, 0.02, 30, 1e-6, 1e-6)
     w = ops.icp_refine(s, t, None, 0.02, 30, 1e-6, 1e-6)
     assert torch.equal(Ti, w["T"]) and torch.equal(fit, w["fitness"]) and torch.equal(its, w["iterations"])
+
+
+def test_pruned_search_soak_over_edge_and_random_sizes():
+    """scripts/soak_pruned.py in a child process: every variant boundary (257, 512/513, ... 2048/2049, 4095/4096), ragged N != M,
+    chunked launches and all four angle bases; the pruned kernel's state and outputs must equal the brute-force kernel's bit for bit."""
+    import subprocess
+    env = dict(os.environ, CASES="64", SEED="11")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "soak_pruned.py")], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "64 cases, 0 mismatches" in r.stdout
