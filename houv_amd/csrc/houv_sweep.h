@@ -142,35 +142,65 @@ __device__ __forceinline__ void block_sum(float (&v)[NV], float* red, float* out
 }
 
 
+// acc = 2 * acc + bit in ONE instruction: v_addc_co_u32 adds the lane's bit of a 64-bit lane mask (the compare's SGPR pair) as
+// carry-in.  Replaces v_cndmask + v_or (+ v_min) wherever per-lane bits are collected: box tests, rescans.
+__device__ __forceinline__ unsigned shift_in_mask(unsigned acc, unsigned long long lanes) {
+  unsigned long long carry_out;
+  asm("v_addc_co_u32_e64 %0, %1, %0, %0, %2" : "+v"(acc), "=s"(carry_out) : "s"(lanes));
+  return acc;
+}
+__device__ __forceinline__ unsigned shift_in(unsigned acc, bool bit) { return shift_in_mask(acc, __builtin_amdgcn_ballot_w64(bit)); }
+
 // Exact NN recovery for one query: re-evaluate the winning 32-reference sub-tile with the bit-identical expression
-// and return the lowest matching reference.  The scan order is rotated per lane (rot = lane id & 31): sub-tile bases
-// are 512 B apart, so an un-rotated scan puts all lanes of a ds_read_b128 group on the same LDS bank quad.  XOR512:
-// the cloud is 512-B aligned in LDS, so the rotation is an XOR on the byte address (one v_xor per read); otherwise
-// it is (j + rot) mod 32.
+// and return the lowest matching reference.  The scan order is rotated per lane: sub-tile bases are 512 B apart, so an
+// un-rotated scan puts all lanes of a ds_read_b128 group on the same LDS bank quad.
+// XOR512 (the cloud is 512-B aligned in LDS): lane l reads slot (i ^ (l & 15)) of BOTH 256-B halves of the sub-tile -- 16
+// distinct slots in each of the instruction's 16-lane groups, one v_xor per TWO reads (the second is an immediate offset) --
+// and collects the matches as one bit per read (shift_in); the lowest matching index is decoded after the scan (one
+// match unless two references tie exactly).  Otherwise: (j + rot) mod 32 with rot = lane & 31, min-tracked.
 template <int MET, int BATCH, bool XOR512 = false>
 __device__ __forceinline__ float4 recover_nn(const float4* __restrict__ rp, float qx, float qy, float qz, float bd, int rot,
                                              int& j_out) {
   int jb = kSub;
-  const unsigned xa = (unsigned)(size_t)(lds_f4)rp + ((unsigned)rot << 4);
+  if constexpr (XOR512) {
+    static_assert(BATCH % 2 == 0 && (kSub / 2) % (BATCH / 2) == 0 && kSub == 32, "reads come in pairs 256 B apart");
+    const unsigned r16 = (unsigned)rot & 15u;
+    const unsigned xa = (unsigned)(size_t)(lds_f4)rp + (r16 << 4);
+    unsigned match = 0u;                          // bit (31 - e) = read e matched; e = 2 * i + half
 #pragma unroll 1
-  for (int c = 0; c < kSub; c += BATCH) {
-    float4 r[BATCH];
+    for (int c = 0; c < kSub / 2; c += BATCH / 2) {
+      float4 r[BATCH];
 #pragma unroll
-    for (int u = 0; u < BATCH; ++u) {
-      if constexpr (XOR512) {
-        const houv_f4v v = *(lds_f4)(size_t)(xa ^ ((unsigned)(c + u) << 4));
-        r[u] = make_float4(v.x, v.y, v.z, v.w);
-      } else {
-        r[u] = rp[(c + u + rot) & (kSub - 1)];
+      for (int u = 0; u < BATCH; u += 2) {
+        lds_f4 p = (lds_f4)(size_t)(xa ^ ((unsigned)(c + u / 2) << 4));
+        const houv_f4v v0 = p[0], v1 = p[kSub / 2];
+        r[u] = make_float4(v0.x, v0.y, v0.z, v0.w);
+        r[u + 1] = make_float4(v1.x, v1.y, v1.z, v1.w);
       }
+#pragma unroll
+      for (int u = 0; u < BATCH; ++u) asm volatile("" ::"v"(r[u].x), "v"(r[u].y), "v"(r[u].z), "v"(r[u].w));   // keep b128
+#pragma unroll
+      for (int u = 0; u < BATCH; ++u)
+        match = shift_in(match, metric_sqdist<MET>(r[u].x - qx, r[u].y - qy, r[u].z - qz) == bd);
     }
+    while (match != 0u) {                         // one round unless references tie (or none: not a point)
+      const int e = __clz((int)match);
+      match &= ~(0x80000000u >> e);
+      jb = min(jb, (int)(((unsigned)(e >> 1) ^ r16) + (unsigned)(e & 1) * (kSub / 2)));
+    }
+  } else {
+#pragma unroll 1
+    for (int c = 0; c < kSub; c += BATCH) {
+      float4 r[BATCH];
 #pragma unroll
-    for (int u = 0; u < BATCH; ++u) asm volatile("" ::"v"(r[u].x), "v"(r[u].y), "v"(r[u].z), "v"(r[u].w));   // keep b128
+      for (int u = 0; u < BATCH; ++u) r[u] = rp[(c + u + rot) & (kSub - 1)];
 #pragma unroll
-    for (int u = 0; u < BATCH; ++u) {
-      const float d = metric_sqdist<MET>(r[u].x - qx, r[u].y - qy, r[u].z - qz);
-      const int j = XOR512 ? ((c + u) ^ rot) : ((c + u + rot) & (kSub - 1));
-      jb = min(jb, (d == bd) ? j : kSub);   // lowest matching index, whatever the order
+      for (int u = 0; u < BATCH; ++u) asm volatile("" ::"v"(r[u].x), "v"(r[u].y), "v"(r[u].z), "v"(r[u].w));   // keep b128
+#pragma unroll
+      for (int u = 0; u < BATCH; ++u) {
+        const float d = metric_sqdist<MET>(r[u].x - qx, r[u].y - qy, r[u].z - qz);
+        jb = min(jb, (d == bd) ? ((c + u + rot) & (kSub - 1)) : kSub);   // lowest matching index, whatever the order
+      }
     }
   }
   j_out = jb & (kSub - 1);
@@ -196,8 +226,14 @@ __device__ __forceinline__ float4 recover_nn(const float4* __restrict__ rp, floa
 // iteration.  The walk is ~60 % of the pruned iteration, the box tests ~10 %, the bounds ~2 %.
 // ---------------------------------------------------------------------------------------------------------------
 #ifdef HOUV_STAMPS
-__device__ unsigned long long g_prune_stat[8];   // asked, steps, waves, cycles: bounds / masks / walk
-#define HOUV_PSTAMP(i) do { const unsigned long long n_ = __builtin_readcyclecounter(); if ((threadIdx.x & 63) == 0) atomicAdd(&g_prune_stat[i], n_ - pst_); pst_ = n_; } while (0)
+// one record per workgroup (modulo kStampWgs), summed on the host: same-address global atomics from every wave at every stamp
+// serialise in L2 (the stamped build ran 2.7x slower than the product, distorting what it measures), and an LDS array would cost the
+// <512,4> variant its second workgroup per CU.  [0..15] solve.hip's phases, [16..23]: asked, steps, waves, cycles of the sweep's phases
+constexpr int kStampWgs = 4096;
+__device__ unsigned long long g_stamp_wg[kStampWgs * 24];
+#define HOUV_STAMP_ADD(i, v) atomicAdd(&g_stamp_wg[(blockIdx.x % kStampWgs) * 24 + (i)], (unsigned long long)(v))
+#define HOUV_PSTAT(i, v) HOUV_STAMP_ADD(16 + (i), v)
+#define HOUV_PSTAMP(i) do { const unsigned long long n_ = __builtin_readcyclecounter(); if ((threadIdx.x & 63) == 0) HOUV_PSTAT(i, n_ - pst_); pst_ = n_; } while (0)
 #else
 #define HOUV_PSTAMP(i) do {} while (0)
 #endif
@@ -215,24 +251,31 @@ __device__ __forceinline__ int pt_index(int k) {
 #endif
 
 // Minimum of the NMET squared distances between G queries and the 32 references of ONE sub-tile, gathered per lane: the lane's
-// sub-tile starts at LDS byte address (xa & ~511); the scan order is rotated per lane by XOR -- reference j sits at byte
-// (j ^ rot) * 16, one v_xor per read; needs the clouds 512-B aligned in LDS (solve.hip aligns the dynamic segment),
-// conflict-free as (lane ^ j) % 16 takes 16 distinct slots in every ds_read_b128 lane group.  The reads are software-
-// pipelined: while a batch of four references is being evaluated the next batch is in flight (ping-pong register sets; the
-// trailing prefetch wraps around and is dropped).  Same expression trees as sweep_tile().
-template <int G, int NMET>
+// sub-tile starts at LDS byte address (xa & ~511); the scan order is rotated per lane by XOR over the 16 slots of a 256-B half --
+// xa carries (lane & 15) << 4 in bits 4..7 -- and both halves are read through one address (the second read is an immediate
+// offset: one v_xor per TWO reads); needs the clouds 512-B aligned in LDS (solve.hip aligns the dynamic segment); conflict-free
+// as (lane ^ i) % 16 takes 16 distinct slots in every ds_read_b128 lane group.  The reads are software-pipelined: while a batch
+// of four references is being evaluated the next batch is in flight (ping-pong register sets; the trailing prefetch wraps
+// around and is dropped).  Same expression trees as sweep_tile(); the order inside a sub-tile does not matter to a minimum.
+// INIT = false: tm comes in holding the running minima (the caller compares against its copy afterwards).
+template <int G, int NMET, bool INIT = true>
 __device__ __forceinline__ void gather_tile_min(unsigned xa, const float (&cx)[G], const float (&cy)[G], const float (&cz)[G],
                                                 float (&tm)[G][NMET]) {
+  if constexpr (INIT) {
 #pragma unroll
-  for (int k = 0; k < G; ++k)
+    for (int k = 0; k < G; ++k)
 #pragma unroll
-    for (int m = 0; m < NMET; ++m) tm[k][m] = INFINITY;
-  constexpr int kBatch = 4;
-  auto fetch = [&](float4 (&r)[kBatch], int j0) {
+      for (int m = 0; m < NMET; ++m) tm[k][m] = INFINITY;
+  }
+  constexpr int kBatch = 4, kHalf = kSub / 2;
+  static_assert(kSub == 32, "two 256-B halves of 16 slots");
+  auto fetch = [&](float4 (&r)[kBatch], int i0) {
 #pragma unroll
-    for (int u = 0; u < kBatch; ++u) {
-      const houv_f4v v = *(lds_f4)(size_t)(xa ^ ((unsigned)((j0 + u) & (kSub - 1)) << 4));
-      r[u] = make_float4(v.x, v.y, v.z, v.w);
+    for (int u = 0; u < kBatch; u += 2) {
+      lds_f4 p = (lds_f4)(size_t)(xa ^ ((unsigned)((i0 + u / 2) & (kHalf - 1)) << 4));
+      const houv_f4v v0 = p[0], v1 = p[kHalf];
+      r[u] = make_float4(v0.x, v0.y, v0.z, v0.w);
+      r[u + 1] = make_float4(v1.x, v1.y, v1.z, v1.w);
     }
   };
   auto eval = [&](float4 (&r)[kBatch]) {
@@ -264,10 +307,10 @@ __device__ __forceinline__ void gather_tile_min(unsigned xa, const float (&cx)[G
   float4 ra[kBatch], rb[kBatch];
   fetch(ra, 0);
 #pragma unroll 1
-  for (int j0 = 0; j0 < kSub; j0 += 2 * kBatch) {
-    fetch(rb, j0 + kBatch);
+  for (int i0 = 0; i0 < kHalf; i0 += kBatch) {
+    fetch(rb, i0 + kBatch / 2);
     eval(ra);
-    fetch(ra, j0 + 2 * kBatch);
+    fetch(ra, i0 + kBatch);
     eval(rb);
   }
 }
@@ -298,22 +341,48 @@ __device__ __forceinline__ void prune_masks(const float4* __restrict__ refs, con
 #pragma unroll
       for (int m = 0; m < NMET; ++m) ub[k][m] = ok ? (ub[k][m] * 1.00001f + 1e-30f) : -1.f;   // box distances are rounded: stay conservative
     }
+    unsigned alo[L], ahi[L];
 #pragma unroll
-    for (int g = 0; g < L; ++g) un[g] = 0ull;
+    for (int g = 0; g < L; ++g) alo[g] = ahi[g] = 0u;
     HOUV_PSTAMP(3);
-    for (int t = 0; t < ntile; ++t) {                 // wave-uniform: box reads are LDS broadcasts
-      const float4 lo = boxes[2 * t], hi = boxes[2 * t + 1];
+    // per query and box (17 instructions; wave-uniform t: the box reads are LDS broadcasts): the box point nearest to the query is
+    // the query clamped into the box (v_med3), its offset squared per axis and summed per metric; the verdicts are collected
+    // one bit per box by shift_in, so the boxes run in DESCENDING order, 32 per mask word
+    auto test = [&](const float4 lo, const float4 hi, unsigned (&acc)[L]) {
 #pragma unroll
-      for (int k = 0; k < Q; ++k) {
-        const float dx = fmaxf(fmaxf(lo.x - qx[k], qx[k] - hi.x), 0.f);
-        const float dy = fmaxf(fmaxf(lo.y - qy[k], qy[k] - hi.y), 0.f);
-        const float dz = fmaxf(fmaxf(lo.z - qz[k], qz[k] - hi.z), 0.f);
-        const float xx = dx * dx, yy = dy * dy, zz = dz * dz;
-        bool in = (xx + yy + zz) <= ub[k][0];
-        if constexpr (NMET == 4) in = in || (yy + zz) <= ub[k][1] || (xx + zz) <= ub[k][2] || (xx + yy) <= ub[k][3];
-        un[k / G] |= in ? (1ull << t) : 0ull;
+      for (int g = 0; g < L; ++g) {
+        unsigned long long in = 0ull;                     // lane masks of the compares, OR-ed on the scalar unit (no branches)
+#pragma unroll
+        for (int k = g * G; k < (g + 1) * G; ++k) {
+          const float dx = qx[k] - __builtin_amdgcn_fmed3f(qx[k], lo.x, hi.x);
+          const float dy = qy[k] - __builtin_amdgcn_fmed3f(qy[k], lo.y, hi.y);
+          const float dz = qz[k] - __builtin_amdgcn_fmed3f(qz[k], lo.z, hi.z);
+          if constexpr (NMET == 4) {
+            const float xx = dx * dx, yy = dy * dy;
+            const float s3 = __builtin_fmaf(dy, dy, xx), s1 = __builtin_fmaf(dz, dz, yy), s2 = __builtin_fmaf(dz, dz, xx);
+            const float s0 = __builtin_fmaf(dz, dz, s3);
+            in |= __builtin_amdgcn_ballot_w64(s0 <= ub[k][0]) | __builtin_amdgcn_ballot_w64(s1 <= ub[k][1]) |
+                  __builtin_amdgcn_ballot_w64(s2 <= ub[k][2]) | __builtin_amdgcn_ballot_w64(s3 <= ub[k][3]);
+          } else {
+            in |= __builtin_amdgcn_ballot_w64(__builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx)) <= ub[k][0]);
+          }
+        }
+        acc[g] = shift_in_mask(acc[g], in);
       }
-    }
+    };
+    auto run = [&](int t_first, int t_last, unsigned (&acc)[L]) {      // t_first >= t_last; the next box is in flight while this one is tested
+      float4 lo = boxes[2 * t_first], hi = boxes[2 * t_first + 1];
+      for (int t = t_first; t >= t_last; --t) {
+        const int tn = t > 0 ? t - 1 : 0;
+        const float4 nlo = boxes[2 * tn], nhi = boxes[2 * tn + 1];
+        test(lo, hi, acc);
+        lo = nlo; hi = nhi;
+      }
+    };
+    if (ntile > 32) run(ntile - 1, 32, ahi);
+    run((ntile < 32 ? ntile : 32) - 1, 0, alo);
+#pragma unroll
+    for (int g = 0; g < L; ++g) un[g] = ((unsigned long long)ahi[g] << 32) | alo[g];
   }
   HOUV_PSTAMP(4);
 }
@@ -367,10 +436,10 @@ __device__ __forceinline__ void pruned_sweep(const float4* __restrict__ refs, co
       all |= u;
     }
     if ((threadIdx.x & 63) == 0) {
-      atomicAdd(&g_prune_stat[0], (unsigned long long)asked);           // sub-tile visits the wave's lanes asked for
-      atomicAdd(&g_prune_stat[2], 1ull);                                // waves
-      atomicAdd(&g_prune_stat[6], (unsigned long long)uni_g);           // sum over lists of the per-list wave unions
-      atomicAdd(&g_prune_stat[7], (unsigned long long)__popcll(all));   // union over the whole wave
+      HOUV_PSTAT(0, (unsigned long long)asked);           // sub-tile visits the wave's lanes asked for
+      HOUV_PSTAT(2, 1ull);                                // waves
+      HOUV_PSTAT(6, (unsigned long long)uni_g);           // sum over lists of the per-list wave unions
+      HOUV_PSTAT(7, (unsigned long long)__popcll(all));   // union over the whole wave
     }
   }
   pst_ = __builtin_readcyclecounter();
@@ -401,7 +470,7 @@ __device__ __forceinline__ void pruned_sweep(const float4* __restrict__ refs, co
         const unsigned long long mm = un[g];
         t = (mm != 0ull) ? (__ffsll((long long)mm) - 1) : t;
         un[g] = mm & (mm - 1ull);                              // 0 stays 0
-        const unsigned xa = (unsigned)(size_t)(lds_f4)refs + (unsigned)t * (kSub * 16u) + ((unsigned)rot << 4);
+        const unsigned xa = (unsigned)(size_t)(lds_f4)refs + (unsigned)t * (kSub * 16u) + (((unsigned)rot & 15u) << 4);
         float tm[G][NMET];
         gather_tile_min<G, NMET>(xa, cx, cy, cz, tm);
 #pragma unroll
@@ -450,7 +519,7 @@ __device__ __forceinline__ void pruned_sweep(const float4* __restrict__ refs, co
         }
       }
     }
-    const unsigned xa = (unsigned)(size_t)(lds_f4)refs + (unsigned)t * (kSub * 16u) + ((unsigned)rot << 4);
+    const unsigned xa = (unsigned)(size_t)(lds_f4)refs + (unsigned)t * (kSub * 16u) + (((unsigned)rot & 15u) << 4);
     float tm[G][NMET];
     gather_tile_min<G, NMET>(xa, cx, cy, cz, tm);
 #pragma unroll
@@ -466,7 +535,7 @@ __device__ __forceinline__ void pruned_sweep(const float4* __restrict__ refs, co
   }
   if (stats && (threadIdx.x & 63) == 0) atomicAdd(&stats[1], (unsigned long long)nsteps);
 #ifdef HOUV_STAMPS
-  if ((threadIdx.x & 63) == 0) atomicAdd(&g_prune_stat[1], steps_);
+  if ((threadIdx.x & 63) == 0) HOUV_PSTAT(1, steps_);
   HOUV_PSTAMP(5);
 #endif
 }
@@ -510,6 +579,10 @@ __device__ __forceinline__ void pruned_sweep_sorted(const float4* __restrict__ r
   const int tid = threadIdx.x, lane = tid & 63;
   unsigned long long un[Q];
   prune_masks<BLOCK, Q, NMET, 1, Q, 1>(refs, boxes, ntile, qx, qy, qz, prev, prev_stride, count, un);
+#ifdef HOUV_STAMPS
+  unsigned long long pst_ = __builtin_readcyclecounter();   // diagnostic build: [3] bounds, [4] box tests, [5] sort, [6] walk, [7] end barrier
+  if ((threadIdx.x & 63) == 0) HOUV_PSTAT(2, 1ull);
+#endif
   int len[Q], rnk[Q];
 #pragma unroll
   for (int k = 0; k < Q; ++k) {
@@ -542,6 +615,7 @@ __device__ __forceinline__ void pruned_sweep_sorted(const float4* __restrict__ r
   __syncthreads();
   const int nblk = (count + 63) >> 6;
   int asked = 0, nsteps = 0;
+  HOUV_PSTAMP(5);
   for (;;) {
     int b = 0;
     if (lane == 0) b = atomicAdd(&st.hist[130], 1);
@@ -568,14 +642,15 @@ __device__ __forceinline__ void pruned_sweep_sorted(const float4* __restrict__ r
 #pragma unroll
       for (int h = 0; h < (1 << TS); ++h) {
         const int ts = (t << TS) | h;                                   // sub-tile
-        const unsigned xa = (unsigned)(size_t)(lds_f4)refs + (unsigned)ts * (kSub * 16u) + ((unsigned)rot << 4);
-        float tm[1][NMET];
-        gather_tile_min<1, NMET>(xa, cx, cy, cz, tm);
+        const unsigned xa = (unsigned)(size_t)(lds_f4)refs + (unsigned)ts * (kSub * 16u) + (((unsigned)rot & 15u) << 4);
+        float tm[1][NMET];                                              // the running minima threaded through the sub-tile
+#pragma unroll
+        for (int m = 0; m < NMET; ++m) tm[0][m] = cb[m];
+        gather_tile_min<1, NMET, false>(xa, cx, cy, cz, tm);
 #pragma unroll
         for (int m = 0; m < NMET; ++m) {
-          const bool lt = tm[0][m] < cb[m];
-          cb[m] = lt ? tm[0][m] : cb[m];
-          ct[m] = lt ? ts : ct[m];
+          ct[m] = (tm[0][m] < cb[m]) ? ts : ct[m];                      // strictly lower than before: this sub-tile holds it
+          cb[m] = tm[0][m];
         }
       }
     }
@@ -597,7 +672,9 @@ __device__ __forceinline__ void pruned_sweep_sorted(const float4* __restrict__ r
       atomicAdd(&stats[2], 1ull);                                       // one wave-sweep = 64 x Q queries, as in the owner walk
     }
   }
+  HOUV_PSTAMP(6);
   __syncthreads();   // the workgroup's waves share one L1: its global stores above are visible to its loads below
+  HOUV_PSTAMP(7);
 #pragma unroll
   for (int k = 0; k < Q; ++k) {
     const int q = pt_index<BLOCK, Q, 1>(k);

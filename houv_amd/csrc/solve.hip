@@ -26,6 +26,9 @@
 //     hence the same bits everywhere downstream, for ~1/8 of the point pairs.
 #include <stddef.h>
 #include <stdlib.h>
+#ifdef HOUV_STAMPS
+#include <vector>
+#endif
 
 #include "../../include/houv_hip.h"
 #include "houv_common.h"
@@ -64,11 +67,10 @@ struct SolveArgs {
 
 #ifdef HOUV_STAMPS
 // Diagnostic build only (scripts/stamps.sh): per-phase wave-cycle totals, never read by the kernel itself.
-__device__ unsigned long long g_stamp[16];
 #define HOUV_STAMP(i)                                                        \
   do {                                                                       \
     const unsigned long long now_ = __builtin_readcyclecounter();           \
-    if ((threadIdx.x & 63) == 0) atomicAdd(&g_stamp[i], now_ - t_stamp_);   \
+    if ((threadIdx.x & 63) == 0) HOUV_STAMP_ADD(i, now_ - t_stamp_);   \
     t_stamp_ = now_;                                                         \
   } while (0)
 #define HOUV_STAMP_PARAM , unsigned long long& t_stamp_
@@ -658,10 +660,10 @@ __global__ __launch_bounds__(BLOCK, (Q == 1 ? 8 : 4)) void solve_kernel(SolveArg
     }
 #ifdef HOUV_STAMPS
     if (tid == 0) {   // prediction statistics: metric-iterations with A rescanned / won by A / repaired / total
-      atomicAdd(&g_stamp[12], (unsigned long long)__popc(grad_a));
-      atomicAdd(&g_stamp[13], (unsigned long long)__popc(pick_a));
-      atomicAdd(&g_stamp[14], (unsigned long long)__popc(pick_a & ~grad_a & kAllMet));
-      atomicAdd(&g_stamp[15], (unsigned long long)NMET);
+      HOUV_STAMP_ADD(12, (unsigned long long)__popc(grad_a));
+      HOUV_STAMP_ADD(13, (unsigned long long)__popc(pick_a));
+      HOUV_STAMP_ADD(14, (unsigned long long)__popc(pick_a & ~grad_a & kAllMet));
+      HOUV_STAMP_ADD(15, (unsigned long long)NMET);
     }
 #endif
     pred_a = pick_a;
@@ -780,22 +782,24 @@ int launch(const SolveArgs& a, int use_views, hipStream_t s) {
 }  // namespace houv
 
 #ifdef HOUV_STAMPS
-extern "C" int houv_debug_read_prune_stats(unsigned long long* host_out, int reset) {
-  if (hipMemcpyFromSymbol(host_out, HIP_SYMBOL(houv::g_prune_stat), sizeof(unsigned long long) * 8) != hipSuccess) return 0;
+// sums of the per-workgroup stamp records (diagnostic build): first = 16 for the sweep's counters, 0 for the kernel's phases
+static int read_stamp_records(unsigned long long* host_out, int first, int n, int reset) {
+  static std::vector<unsigned long long> h(houv::kStampWgs * 24);
+  if (hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(houv::g_stamp_wg), h.size() * sizeof(unsigned long long)) != hipSuccess) return 0;
+  for (int i = 0; i < n; ++i) {
+    unsigned long long acc = 0ull;
+    for (int w = 0; w < houv::kStampWgs; ++w) acc += h[(size_t)w * 24 + first + i];
+    host_out[i] = acc;
+  }
   if (reset) {
-    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (hipMemcpyToSymbol(HIP_SYMBOL(houv::g_prune_stat), z, sizeof(z)) != hipSuccess) return 0;
+    for (int w = 0; w < houv::kStampWgs; ++w)
+      for (int i = 0; i < n; ++i) h[(size_t)w * 24 + first + i] = 0ull;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(houv::g_stamp_wg), h.data(), h.size() * sizeof(unsigned long long)) != hipSuccess) return 0;
   }
   return 1;
 }
-extern "C" int houv_debug_read_stamps(unsigned long long* host_out, int reset) {
-  if (hipMemcpyFromSymbol(host_out, HIP_SYMBOL(houv::g_stamp), sizeof(unsigned long long) * 16) != hipSuccess) return 0;
-  if (reset) {
-    unsigned long long z[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    if (hipMemcpyToSymbol(HIP_SYMBOL(houv::g_stamp), z, sizeof(z)) != hipSuccess) return 0;
-  }
-  return 1;
-}
+extern "C" int houv_debug_read_prune_stats(unsigned long long* host_out, int reset) { return read_stamp_records(host_out, 16, 8, reset); }
+extern "C" int houv_debug_read_stamps(unsigned long long* host_out, int reset) { return read_stamp_records(host_out, 0, 16, reset); }
 #endif
 
 // pruned mode: consecutive points a lane owns per chunk (pt_index), for kernels with Q = 2 / Q = 4 points per lane
