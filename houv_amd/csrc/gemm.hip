@@ -199,6 +199,161 @@ __global__ __launch_bounds__(NWM * 128, WPE) void gemm_f32_kernel(GemmArgs g) {
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// fp32 GEMM on the bf16 matrix pipe: every operand element is split into three bf16 parts, x = hi + mid + lo (round-to-nearest
+// at each step, so the parts carry 8 + 8 + 8 significant bits and the residuals are exact in fp32), and the product is
+// accumulated in fp32 from the part products whose weight is >= 2^-16 of the leading one:
+//   NPROD = 6:  hi*hi + hi*mid + mid*hi + hi*lo + mid*mid + lo*hi     (dropped terms <= 2^-24 relative: the size of an fp32 rounding)
+//   NPROD = 3:  hi*hi + hi*mid + mid*hi                               (<= 2^-16 relative: 32x finer than TF32)
+// bf16 x bf16 is exact in fp32 and v_mfma_f32_32x32x16_bf16 accumulates in fp32, so NPROD = 6 is an fp32 GEMM to within a small
+// multiple of the fp32 MFMA kernel's own rounding error (tests/test_gpu_dcp_ops.py measures both against fp64).  The matrix pipe
+// runs bf16 at 16x the fp32-input rate (MI355X_MICROARCH.md, Matrix cores), so six products cost 6/16 of the fp32 MFMA time.
+// A tile's elements are split ONCE, while it is staged into LDS (5.5 VALU instructions per element, in the MFMAs' shadow):
+// three bf16 planes per operand, rows of 32 k padded to 80 bytes so that the 16 lanes of a ds_read_b128 group (16 rows) hit 16
+// distinct 16-byte slots; an MFMA operand fragment (8 consecutive k of one row) is one ds_read_b128 per plane.
+// Full, 16-byte aligned tiles and B given as [N,K] (every DCP linear / 1x1 convolution / score product); anything else runs
+// the fp32-input kernel above.  Inf in an operand yields NaN (Inf - Inf in the residual), where the fp32 kernel yields Inf.
+// ---------------------------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ unsigned pack_bf16(float a, float b) {   // v_cvt_pk_bf16_f32: a in the low half
+  const f32x2 p = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(p, bf16x2));
+}
+__device__ __forceinline__ float bf16_lo_as_f32(unsigned pk) { return __builtin_bit_cast(float, pk << 16); }
+__device__ __forceinline__ float bf16_hi_as_f32(unsigned pk) { return __builtin_bit_cast(float, pk & 0xffff0000u); }
+
+// four consecutive k of one row -> 8 bytes per plane
+template <int NPART>
+__device__ __forceinline__ void split4(const float4 v, uint2 (&out)[NPART]) {
+  float r0 = v.x, r1 = v.y, r2 = v.z, r3 = v.w;
+#pragma unroll
+  for (int p = 0; p < NPART; ++p) {
+    const unsigned a = pack_bf16(r0, r1), b = pack_bf16(r2, r3);
+    out[p] = make_uint2(a, b);
+    if (p + 1 < NPART) {
+      r0 -= bf16_lo_as_f32(a); r1 -= bf16_hi_as_f32(a);
+      r2 -= bf16_lo_as_f32(b); r3 -= bf16_hi_as_f32(b);
+    }
+  }
+}
+
+template <int BN, int NPROD>
+__global__ __launch_bounds__(512, 2) void gemm_split_kernel(GemmArgs g) {
+  static_assert(NPROD == 6 || NPROD == 3, "six products (fp32-grade) or three (2^-16)");
+  constexpr int NPART = NPROD == 6 ? 3 : 2;
+  constexpr int NT = 512, NWM = 4;
+  constexpr int MI = BM / (32 * NWM);                  // 1
+  constexpr int NI = BN / 64;                          // 32-wide MFMA tiles per wave along N
+  constexpr int ROWB = 80;                             // bytes per LDS row: 32 bf16 + 16 B of padding
+  constexpr int QK = BK / 4, RPI = NT / QK;            // 8 k-quads per row, 64 rows per pass
+  constexpr int AREG = BM * BK / 4 / NT, BREG = BN * BK / 4 / NT;
+  __shared__ __attribute__((aligned(16))) unsigned char As[NPART][BM * ROWB];
+  __shared__ __attribute__((aligned(16))) unsigned char Bs[NPART][BN * ROWB];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int zo = blockIdx.z / g.inner, zi = blockIdx.z - zo * g.inner;
+  const float* __restrict__ A = g.A + zo * g.sAo + zi * g.sAi;
+  const float* __restrict__ B = g.B + zo * g.sBo + zi * g.sBi;
+  float* __restrict__ C = g.C + zo * g.sCo + zi * g.sCi;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+
+  f32x16 acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  float4 ra[AREG], rb[BREG];
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < AREG; ++i)
+      ra[i] = *reinterpret_cast<const float4*>(A + (size_t)(m0 + tid / QK + RPI * i) * g.lda + k0 + (tid % QK) * 4);
+#pragma unroll
+    for (int i = 0; i < BREG; ++i)
+      rb[i] = *reinterpret_cast<const float4*>(B + (size_t)(n0 + tid / QK + RPI * i) * g.ldb + k0 + (tid % QK) * 4);
+  };
+  auto stage = [&]() {
+#pragma unroll
+    for (int i = 0; i < AREG; ++i) {
+      uint2 parts[NPART];
+      split4<NPART>(ra[i], parts);
+      const int off = (tid / QK + RPI * i) * ROWB + (tid % QK) * 8;
+#pragma unroll
+      for (int p = 0; p < NPART; ++p) *reinterpret_cast<uint2*>(&As[p][off]) = parts[p];
+    }
+#pragma unroll
+    for (int i = 0; i < BREG; ++i) {
+      uint2 parts[NPART];
+      split4<NPART>(rb[i], parts);
+      const int off = (tid / QK + RPI * i) * ROWB + (tid % QK) * 8;
+#pragma unroll
+      for (int p = 0; p < NPART; ++p) *reinterpret_cast<uint2*>(&Bs[p][off]) = parts[p];
+    }
+  };
+
+  const int kh = lane >> 5, rl = lane & 31;
+  fetch(0);
+  for (int k0 = 0; k0 < g.K; k0 += BK) {
+    __syncthreads();          // previous tile fully consumed
+    stage();
+    __syncthreads();
+    if (k0 + BK < g.K) fetch(k0 + BK);     // the next tile travels while this one is multiplied
+#pragma unroll
+    for (int s = 0; s < BK / 16; ++s) {
+      bf16x8 a[MI][NPART], b[NI][NPART];
+#pragma unroll
+      for (int p = 0; p < NPART; ++p) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+          a[i][p] = *reinterpret_cast<const bf16x8*>(&As[p][(wm * (32 * MI) + i * 32 + rl) * ROWB + s * 32 + kh * 16]);
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+          b[j][p] = *reinterpret_cast<const bf16x8*>(&Bs[p][(wn * (BN / 2) + j * 32 + rl) * ROWB + s * 32 + kh * 16]);
+      }
+      // smallest terms first; (pa, pb) = part indices of A and B
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+          if constexpr (NPROD == 6) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[j][0], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][2], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][1], acc[i][j], 0, 0, 0);
+          }
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][0], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][1], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][0], acc[i][j], 0, 0, 0);
+        }
+    }
+  }
+
+  const float* __restrict__ Rsd = g.residual ? g.residual + zo * g.sRo + zi * g.sRi : nullptr;
+#pragma unroll
+  for (int j = 0; j < NI; ++j) {
+    const int col = n0 + wn * (BN / 2) + j * 32 + (lane & 31);
+    const float sc = g.scale ? g.scale[col] : 1.0f;
+    const float sh = g.shift ? g.shift[col] : 0.0f;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * (32 * MI) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        float v = acc[i][j][r] * g.alpha;
+        v = v * sc + sh;
+        if (Rsd) v += Rsd[(size_t)row * g.ldr + col];
+        if (g.relu) v = fmaxf(v, 0.f);
+        C[(size_t)row * g.ldc + col] = v;
+      }
+    }
+  }
+}
+
 }  // namespace
 }  // namespace houv
 
@@ -244,6 +399,12 @@ extern "C" int houv_gemm_f32(const float* A, const float* B, float* C, int M, in
                            !((lda | ldb | (int)(sAo & 3) | (int)(sAi & 3) | (int)(sBo & 3) | (int)(sBi & 3)) & 3);
     const bool force_guard = g_debug.gemm_guarded.load() != 0;   // diagnostics / A-B only
     const bool full = !force_guard && aligned16 && M % BM == 0 && N % bn == 0 && K % BK == 0;
+    const int split = g_debug.gemm_split.load();               // 0: fp32-input MFMA; 6 / 3: bf16 part products (see gemm_split_kernel)
+    if (split && full && trans_b) {
+      if (narrow) { if (split == 6) gemm_split_kernel<64, 6><<<grid, 512, 0, s>>>(g); else gemm_split_kernel<64, 3><<<grid, 512, 0, s>>>(g); }
+      else { if (split == 6) gemm_split_kernel<128, 6><<<grid, 512, 0, s>>>(g); else gemm_split_kernel<128, 3><<<grid, 512, 0, s>>>(g); }
+      return check_launch("houv_gemm_f32") ? 1 : 0;
+    }
     if (narrow) {
       if (trans_b) { if (full) gemm_f32_kernel<64, true, 6, 4, false><<<grid, 512, 0, s>>>(g); else gemm_f32_kernel<64, true, 6, 4><<<grid, 512, 0, s>>>(g); }
       else { if (full) gemm_f32_kernel<64, false, 6, 4, false><<<grid, 512, 0, s>>>(g); else gemm_f32_kernel<64, false, 6, 4><<<grid, 512, 0, s>>>(g); }

@@ -35,6 +35,7 @@ inline bool check_launch(const char* what) {
 //   "chamfer_direct"  1: houv_chamfer_forward runs the direct sweep instead of the filtered one (same bits)
 //   "chamfer_q"       queries per lane cap of the filtered Chamfer kernel (8)
 //   "gemm_4w" / "gemm_guarded"   houv_gemm_f32: 4-wave workgroups / always the guarded tile fetch
+//   "gemm_split"      houv_gemm_f32: 0 fp32-input MFMA, 6 / 3 = bf16 part products per fp32 product (gemm.hip, gemm_split_kernel)
 struct DebugKnobs {
   std::atomic<int> pred_mode{0};
   std::atomic<int> ws_refresh{4};
@@ -46,6 +47,7 @@ struct DebugKnobs {
   std::atomic<int> chamfer_q{8};
   std::atomic<int> gemm_4w{0};
   std::atomic<int> gemm_guarded{0};
+  std::atomic<int> gemm_split{6};        // houv_gemm_f32 on the bf16 matrix pipe: 6 / 3 part products per fp32 product (0: fp32-input MFMA)
 };
 extern DebugKnobs g_debug;
 

@@ -54,6 +54,31 @@ def test_gemm_plain(dev, M, N, K, tb):
         np.testing.assert_array_equal(ops.gemm(I, B, trans_b=True).cpu().numpy(), B.t().cpu().numpy())
 
 
+@pytest.mark.parametrize("M,N,K", [(1024, 512, 512), (2048, 128, 64), (256, 64, 64), (384, 256, 1024)])
+def test_gemm_on_the_bf16_pipe_is_fp32_grade(dev, M, N, K):
+    """houv_gemm_f32's default for full tiles: every fp32 operand split into three bf16 parts, six part products per product
+    (gemm.hip, gemm_split_kernel).  Its error against a float64 product, in units of sum_k |a||b|, must stay within 1.5x the
+    fp32-input MFMA kernel's (measured: 0.85x); the three-product form is 2^-16-grade; an identity operand reproduces B exactly."""
+    from houv_amd import _lib, ops
+    gen = torch.Generator().manual_seed(M + N + K)
+    A = (torch.randn(M, K, generator=gen) * torch.rand(M, 1, generator=gen).mul(6).exp()).to(dev)    # rows of very different scale
+    B = torch.randn(N, K, generator=gen).to(dev)
+    ref = A.double() @ B.double().t()
+    unit = A.double().abs() @ B.double().abs().t()
+    err = {}
+    try:
+        for mode in (0, 6, 3):
+            _lib.debug_set("gemm_split", mode)
+            err[mode] = float(((ops.gemm(A, B, trans_b=True).double() - ref).abs() / unit).max())
+        _lib.debug_set("gemm_split", 6)
+        if M >= K and K % 32 == 0:
+            I = torch.eye(M, K, device=dev)
+            np.testing.assert_array_equal(ops.gemm(I, B, trans_b=True)[:K].cpu().numpy(), B.t().cpu().numpy())
+    finally:
+        _lib.debug_set("gemm_split", 6)
+    assert err[0] < 8e-7 and err[6] < 1.5 * err[0] and err[3] < 2e-5, err
+
+
 def test_gemm_epilogue_and_batched_strided(dev):
     from houv_amd import ops
     gen = torch.Generator().manual_seed(5)
