@@ -19,6 +19,7 @@
 #include <cstdlib>
 #include "../../include/houv_hip.h"
 #include "houv_common.h"
+#include "houv_split.h"
 
 namespace houv {
 namespace {
@@ -215,32 +216,6 @@ __global__ __launch_bounds__(NWM * 128, WPE) void gemm_f32_kernel(GemmArgs g) {
 // Full, 16-byte aligned tiles and B given as [N,K] (every DCP linear / 1x1 convolution / score product); anything else runs
 // the fp32-input kernel above.  Inf in an operand yields NaN (Inf - Inf in the residual), where the fp32 kernel yields Inf.
 // ---------------------------------------------------------------------------------------------------------------
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-
-__device__ __forceinline__ unsigned pack_bf16(float a, float b) {   // v_cvt_pk_bf16_f32: a in the low half
-  const f32x2 p = {a, b};
-  return __builtin_bit_cast(unsigned, __builtin_convertvector(p, bf16x2));
-}
-__device__ __forceinline__ float bf16_lo_as_f32(unsigned pk) { return __builtin_bit_cast(float, pk << 16); }
-__device__ __forceinline__ float bf16_hi_as_f32(unsigned pk) { return __builtin_bit_cast(float, pk & 0xffff0000u); }
-
-// four consecutive k of one row -> 8 bytes per plane
-template <int NPART>
-__device__ __forceinline__ void split4(const float4 v, uint2 (&out)[NPART]) {
-  float r0 = v.x, r1 = v.y, r2 = v.z, r3 = v.w;
-#pragma unroll
-  for (int p = 0; p < NPART; ++p) {
-    const unsigned a = pack_bf16(r0, r1), b = pack_bf16(r2, r3);
-    out[p] = make_uint2(a, b);
-    if (p + 1 < NPART) {
-      r0 -= bf16_lo_as_f32(a); r1 -= bf16_hi_as_f32(a);
-      r2 -= bf16_lo_as_f32(b); r3 -= bf16_hi_as_f32(b);
-    }
-  }
-}
-
 template <int BN, int NPROD>
 __global__ __launch_bounds__(512, 2) void gemm_split_kernel(GemmArgs g) {
   static_assert(NPROD == 6 || NPROD == 3, "six products (fp32-grade) or three (2^-16)");

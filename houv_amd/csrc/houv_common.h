@@ -47,6 +47,7 @@ struct DebugKnobs {
   std::atomic<int> chamfer_q{8};
   std::atomic<int> gemm_4w{0};
   std::atomic<int> gemm_guarded{0};
+  std::atomic<int> attn_split{1};        // houv_attention_f32 on the bf16 matrix pipe (attention.hip, attention_split_kernel); 0: fp32-input MFMA
   std::atomic<int> gemm_split{6};        // houv_gemm_f32 on the bf16 matrix pipe: 6 / 3 part products per fp32 product (0: fp32-input MFMA)
 };
 extern DebugKnobs g_debug;
