@@ -35,6 +35,7 @@ import torch.distributed as dist
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+BF16_PEAK_TFLOPS = 2500.0      # dense bf16 MFMA peak (MI355X_MICROARCH.md, Matrix cores)
 FP32_PEAK_TFLOPS = 157.3     # MI355X fp32 vector == fp32-input MFMA peak (MI355X_MICROARCH.md, chip-level table)
 HBM_PEAK_GBPS = 8000.0
 FLOP_PER_EVAL = 8            # 3 sub + 1 mul + 2 fma per squared distance
@@ -352,9 +353,18 @@ def bench_dcp(args, dev, world, rank):
                                f"batch {P}/GPU (BASELINE configs[4])", "pairs_per_gpu": P, "points": args.points,
                    "parallelism": f"dp{world}"},
         "quality": {"mean_houv_loss_of_dcp_answer": float(np.mean(losses[-args.steps:]))},
-        "roofline": {"kernel": "houv::gemm_f32_kernel + houv::attention_f32_kernel (v_mfma_f32_32x32x2_f32)", "bound": "mfma",
-                     "achieved": g_fl / (g_ms * 1e-3) / 1e12, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": g_fl / (g_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, "traffic": None, "launches": len(log),
+        # the GEMMs and the attention run on the bf16 matrix pipe with every fp32 product summed from SIX bf16 part products
+        # (houv_split.h): the pipe executes 6 bf16 flops per useful fp32 flop, so `achieved` / `frac` price the executed work against
+        # the dense bf16 peak and `useful_fp32_tflops` says what the model got out of it (the fp32-input MFMA peak is 157.3)
+        "roofline": {"kernel": "houv::gemm_split_kernel<.., 6> + houv::attention_split_kernel (v_mfma_f32_32x32x16_bf16, six bf16 "
+                               "part products per fp32 product)", "bound": "mfma",
+                     "achieved": 6.0 * g_fl / (g_ms * 1e-3) / 1e12, "peak": BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": 6.0 * g_fl / (g_ms * 1e-3) / 1e12 / BF16_PEAK_TFLOPS,
+                     "useful_fp32_tflops": g_fl / (g_ms * 1e-3) / 1e12,
+                     "useful_over_fp32_input_mfma_peak": g_fl / (g_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS,
+                     "note": "HIP-event time of every houv_gemm_f32 / houv_attention_f32 call (the attention's split pre-pass included); "
+                             "the short-K 1x1 convolutions of the DGCNN are HBM-bound inside it (DESIGN.md 9.2)",
+                     "traffic": None, "launches": len(log),
                      "avg_launch_ms": g_ms / max(len(log), 1), "kernel_time_share": g_ms * 1e-3 / dt},
     }
     if rank == 0:

@@ -164,7 +164,7 @@ __global__ __launch_bounds__(256, 2) void attention_f32_kernel(AttnArgs g) {
 // The same attention on the bf16 matrix pipe (houv_split.h): Q, K, V and the probabilities are split into three bf16 parts and
 // both products are summed from six part products in fp32 -- fp32-grade results (tests/test_gpu_dcp.py: the same 2e-5 against a
 // float64 reference) at 6/16 of the fp32-input MFMA time.
-//   * a pre-pass splits K and V once per call (every query tile reads them): K planes [pair][head][part][key][128 dims], V planes
+//   * a pre-pass (attention_split_k_kernel, attention_split_v_kernel) splits K and V once per call (every query tile reads them): K planes [pair][head][part][key][128 dims], V planes
 //     TRANSPOSED [pair][head][part][128 dims][key'], keys permuted inside every group of 16 (quads 1 and 2 swapped) so that an
 //     operand fragment of V^T is 8 consecutive bf16 -- see (c);
 //   * Q is split by the workgroup itself, once, into registers: lane (query, half) holds dims 16 s + 8 half .. +7 of every step s;
@@ -187,36 +187,53 @@ struct AttnSplitArgs {
   float scale;
 };
 
-// pre-pass: one thread = 8 dims of one key (K) and 8 keys of one dim (V)
-__global__ __launch_bounds__(256) void attention_split_kv_kernel(const float* __restrict__ K, const float* __restrict__ V, int Nk,
-                                                                 int ldk, int ldv, long long sK, long long sV, int H,
-                                                                 unsigned char* __restrict__ Kp, unsigned char* __restrict__ Vp) {
+// pre-pass, K: one thread = 8 consecutive dims of one key (16-byte loads and stores, both coalesced)
+__global__ __launch_bounds__(256) void attention_split_k_kernel(const float* __restrict__ K, int Nk, int ldk, long long sK, int H,
+                                                                unsigned char* __restrict__ Kp) {
   const int head = blockIdx.y, pair = blockIdx.z;
   const size_t plane = (size_t)Nk * kDk * 2;                                    // bytes of one part of one (pair, head)
   unsigned char* kp = Kp + ((size_t)pair * H + head) * 3 * plane;
-  unsigned char* vp = Vp + ((size_t)pair * H + head) * 3 * plane;
   const int t = blockIdx.x * 256 + threadIdx.x;                                 // Nk * 16 threads
   if (t >= Nk * 16) return;
-  {
-    const int key = t >> 4, oct = t & 15;
-    const float* src = K + pair * sK + (size_t)key * ldk + head * kDk + oct * 8;
-    const float4 a = *reinterpret_cast<const float4*>(src), b = *reinterpret_cast<const float4*>(src + 4);
-    const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-    uint4 parts[3];
-    split8<3>(v, parts);
+  const int key = t >> 4, oct = t & 15;
+  const float* src = K + pair * sK + (size_t)key * ldk + head * kDk + oct * 8;
+  const float4 a = *reinterpret_cast<const float4*>(src), b = *reinterpret_cast<const float4*>(src + 4);
+  const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+  uint4 parts[3];
+  split8<3>(v, parts);
 #pragma unroll
-    for (int p = 0; p < 3; ++p) *reinterpret_cast<uint4*>(kp + p * plane + ((size_t)key * kDk + oct * 8) * 2) = parts[p];
+  for (int p = 0; p < 3; ++p) *reinterpret_cast<uint4*>(kp + p * plane + ((size_t)key * kDk + oct * 8) * 2) = parts[p];
+}
+
+// pre-pass, V: a workgroup transposes 64 keys x 128 dims through LDS -- rows of V are read with coalesced float4 loads, and every
+// (dim, 8-key slot group) fragment is written as 16 bytes with the 8 groups of a dim side by side (128-byte runs per dim and part)
+__global__ __launch_bounds__(256) void attention_split_v_kernel(const float* __restrict__ V, int Nk, int ldv, long long sV, int H,
+                                                                unsigned char* __restrict__ Vp) {
+  constexpr int kKeys = 64, kLd = kKeys + 1;
+  __shared__ float T[kDk * kLd];                                                // T[dim][key]
+  const int head = blockIdx.y, pair = blockIdx.z, k0 = blockIdx.x * kKeys, tid = threadIdx.x;
+  const size_t plane = (size_t)Nk * kDk * 2;
+  unsigned char* vp = Vp + ((size_t)pair * H + head) * 3 * plane;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int idx = tid + 256 * i, key = idx >> 5, d = (idx & 31) * 4;
+    const float4 v = (k0 + key < Nk) ? *reinterpret_cast<const float4*>(V + pair * sV + (size_t)(k0 + key) * ldv + head * kDk + d)
+                                     : make_float4(0.f, 0.f, 0.f, 0.f);
+    T[(d + 0) * kLd + key] = v.x; T[(d + 1) * kLd + key] = v.y; T[(d + 2) * kLd + key] = v.z; T[(d + 3) * kLd + key] = v.w;
   }
-  {
-    const int dim = t & (kDk - 1), oct = t >> 7;                                // lanes = consecutive dims: coalesced reads of V rows
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int oct = tid & 7, dim = (tid >> 3) + 32 * i;
     const int base = (oct >> 1) * 16 + 4 * (oct & 1);                           // slot (half = oct & 1, j) <- key base + 8 (j >> 2) + (j & 3)
+    if (k0 + (oct >> 1) * 16 >= Nk) continue;                                   // Nk is a multiple of 32: whole 16-key groups
     float v[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = V[pair * sV + (size_t)(base + 8 * (j >> 2) + (j & 3)) * ldv + head * kDk + dim];
+    for (int j = 0; j < 8; ++j) v[j] = T[dim * kLd + base + 8 * (j >> 2) + (j & 3)];
     uint4 parts[3];
     split8<3>(v, parts);
 #pragma unroll
-    for (int p = 0; p < 3; ++p) *reinterpret_cast<uint4*>(vp + p * plane + ((size_t)dim * Nk + oct * 8) * 2) = parts[p];
+    for (int p = 0; p < 3; ++p) *reinterpret_cast<uint4*>(vp + p * plane + ((size_t)dim * Nk + k0 + oct * 8) * 2) = parts[p];
   }
 }
 
@@ -411,7 +428,8 @@ extern "C" int houv_attention_f32(const float* Q, const float* K, const float* V
       if (hipDeviceGetDefaultMemPool(&pool, devid) == hipSuccess) (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
     }
     if (hipMallocAsync(reinterpret_cast<void**>(&ws), 2 * bytes, (hipStream_t)stream) == hipSuccess && ws) {
-      attention_split_kv_kernel<<<dim3((Nk * 16 + 255) / 256, H, P), 256, 0, (hipStream_t)stream>>>(K, V, Nk, ldk, ldv, sK, sV, H, ws, ws + bytes);
+      attention_split_k_kernel<<<dim3((Nk * 16 + 255) / 256, H, P), 256, 0, (hipStream_t)stream>>>(K, Nk, ldk, sK, H, ws);
+      attention_split_v_kernel<<<dim3((Nk + 63) / 64, H, P), 256, 0, (hipStream_t)stream>>>(V, Nk, ldv, sV, H, ws + bytes);
       AttnSplitArgs a{Q, O, ws, ws + bytes, Nq, Nk, ldq, ldo, H, sQ, sO, scale};
       attention_split_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(a);
       const bool ok = check_launch("houv_attention_f32");
