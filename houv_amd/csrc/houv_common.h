@@ -36,6 +36,7 @@ inline bool check_launch(const char* what) {
 //   "chamfer_q"       queries per lane cap of the filtered Chamfer kernel (8)
 //   "gemm_4w" / "gemm_guarded"   houv_gemm_f32: 4-wave workgroups / always the guarded tile fetch
 //   "gemm_split"      houv_gemm_f32: 0 fp32-input MFMA, 6 / 3 = bf16 part products per fp32 product (gemm.hip, gemm_split_kernel)
+//   "attn_split"      houv_attention_f32: 1 bf16 matrix pipe with three-part splits (full tiles), 0 fp32-input MFMA kernel
 struct DebugKnobs {
   std::atomic<int> pred_mode{0};
   std::atomic<int> ws_refresh{4};

@@ -170,9 +170,12 @@ int houv_edgeconv1(const float* xyz, const int32_t* idx, int B, int N, int k, co
 /* dcp.py:287/290/293/296 `x.max(dim=-1)`: out[p*ldo + c] = max_j act[(p*k+j)*C + c], p < npts (C, ldo multiples of 4). */
 int houv_max_over_k(const float* act, long long npts, int k, int C, float* out, int ldo, void* stream);
 
-/* fp32 MFMA GEMM with fused epilogue (1x1 conv / nn.Linear / attention products):
+/* fp32 GEMM on the matrix pipe with fused epilogue (1x1 conv / nn.Linear / attention products):
  *   C = relu?( (alpha * A[M,K] op(B)) * scale[n] + shift[n] + residual[m,n] ),  trans_b=1: B is [N,K] (C = A B^T), 0: [K,N].
- * Batched over outer*inner problems with element strides (s?o, s?i).  scale/shift/residual may be NULL. */
+ * Batched over outer*inner problems with element strides (s?o, s?i).  scale/shift/residual may be NULL.
+ * fp32 in, fp32 out, fp32-grade products: full, 16-byte aligned [N,K] tiles run on the bf16 MFMAs with every operand split into
+ * three bf16 parts and six part products per product (error at or below the fp32-input MFMA kernel's, which serves every other
+ * shape); an Inf operand yields NaN there.  houv_debug_set("gemm_split", 0) selects the fp32-input kernel everywhere. */
 int houv_gemm_f32(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
                   int trans_b, int outer, int inner, long long sAo, long long sAi, long long sBo, long long sBi,
                   long long sCo, long long sCi, float alpha, const float* scale_or_null, const float* shift_or_null,
@@ -180,7 +183,10 @@ int houv_gemm_f32(const float* A, const float* B, float* C, int M, int N, int K,
 
 /* dcp.py:26-32 `attention` of MultiHeadedAttention (:198-229), fused: O = softmax(Q K^T * scale) V per (pair, head); the
  * [Nq,Nk] scores stay on chip (online softmax).  Token-major operands: head h of row n of pair p starts at
- * X + p*sX + n*ldX + h*dk.  dk must be 128 (DCP: 512 / 4 heads); strides multiples of 4 floats, pointers 16-byte aligned. */
+ * X + p*sX + n*ldX + h*dk.  dk must be 128 (DCP: 512 / 4 heads); strides multiples of 4 floats, pointers 16-byte aligned.
+ * Full tiles (Nq % 128 == 0, Nk % 32 == 0) run on the bf16 MFMAs with three-part operand splits (fp32-grade, as houv_gemm_f32) and
+ * take a stream-ordered workspace of 12 * P * H * Nk * 128 bytes (hipMallocAsync / hipFreeAsync on `stream`; without it, or with
+ * houv_debug_set("attn_split", 0), the fp32-input kernel runs). */
 int houv_attention_f32(const float* Q, const float* K, const float* V, float* O, int P, int H, int Nq, int Nk, int dk,
                        int ldq, int ldk, int ldv, int ldo, long long sQ, long long sK, long long sV, long long sO,
                        float scale, void* stream);
