@@ -190,6 +190,29 @@ def test_model_is_the_same_with_and_without_fused_attention(dev, monkeypatch):
     np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), atol=2e-4)
 
 
+def test_graph_replayed_chunks_equal_eager_ones(dev):
+    """Model.registration replays a chunk's launches as one HIP graph from the chunk shape's third occurrence on (first: eager,
+    second: capture); answers must equal the eager ones bit for bit, also after the weights change (new capture)."""
+    net = _model(dev)
+    net.pairs_per_chunk = 2
+    gen = torch.Generator().manual_seed(77)
+    src = torch.rand(8, 256, 3, generator=gen).to(dev)
+    tgt = torch.rand(8, 256, 3, generator=gen).to(dev)
+    net.use_graphs = False
+    want = net(src, tgt)
+    net.use_graphs = True
+    got = net(src, tgt)                              # chunks 1 (eager), 2 (capture), 3-4 (replay)
+    assert net.use_graphs and any(e["graph"] is not None for e in net._graphs.values()), "capture fell back to eager"
+    assert torch.equal(got, want)
+    assert torch.equal(net(src.flip(0), tgt.flip(0)), want.flip(0))          # replay on other inputs
+    with torch.no_grad():
+        net.emb_nn.conv2.weight.mul_(1.01)           # a new version of a weight: the old graph must not be replayed
+    net.use_graphs = False
+    want2 = net(src, tgt)
+    net.use_graphs = True
+    assert torch.equal(net(src, tgt), want2) and not torch.equal(want2, want)
+
+
 def test_state_dict_names_equal_reference():
     from houv_amd.models.dcp import Model
     mine = {k for k in Model(None).state_dict() if not k.endswith("num_batches_tracked") and k != "head.reflect"}
