@@ -6,7 +6,7 @@ sys.path.insert(0, ROOT)
 import numpy as np, torch
 from houv_amd import _lib, solver, synthetic
 dev = torch.device("cuda:0")
-P, K, N, iters = int(os.environ.get("P", 32)), 64, 2048, int(os.environ.get("ITERS", 10))
+P, K, N, iters = int(os.environ.get("P", 32)), 64, int(os.environ.get("N", 2048)), int(os.environ.get("ITERS", 10))
 src, tgt, _ = synthetic.make_pairs(P, N, seed=1)
 src, tgt = src.to(dev), tgt.to(dev)
 p0 = solver.houv_init_params(P * K)
