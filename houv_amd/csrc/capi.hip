@@ -66,7 +66,8 @@ extern "C" int houv_debug_set(const char* name, long long value) {
       {"prune_cap_slack", &g_debug.prune_cap_slack, -1, 64}, {"prune_owner_walk", &g_debug.prune_owner_walk, 0, 1}, {"prune_min_points", &g_debug.prune_min_points, 257, 2049},
       {"chamfer_direct", &g_debug.chamfer_direct, 0, 1}, {"chamfer_q", &g_debug.chamfer_q, 1, 8},
       {"gemm_4w", &g_debug.gemm_4w, 0, 1},           {"gemm_guarded", &g_debug.gemm_guarded, 0, 1},
-      {"gemm_split", &g_debug.gemm_split, 0, 6},     {"attn_split", &g_debug.attn_split, 0, 1}};
+      {"gemm_split", &g_debug.gemm_split, 0, 6},     {"attn_split", &g_debug.attn_split, 0, 1},
+      {"knn_split", &g_debug.knn_split, 0, 1}};
   if (name && !strcmp(name, "solve_stats")) {
     g_debug.stats = (unsigned long long)value;
     return 1;

@@ -78,6 +78,96 @@ __global__ __launch_bounds__(256) void knn_kernel(const float* __restrict__ xyz,
   }
 }
 
+// The same search with the REFERENCES split four ways (round 3): the kernel above puts one wave on 64 queries x all N references --
+// at 16 clouds x 2048 points that is 512 waves for 1024 SIMDs, each running for 380 us.  Here a workgroup of four waves owns 64
+// queries; wave w scans the w-th quarter of the references (its own LDS stage, same queue / flush), the four sorted partial lists
+// meet in LDS and wave 0 merges them (20 steps over four list heads).  A partial list is sorted by (distance, index) -- insertion in
+// scan order with strict < --, the merge takes the smallest head and on ties the lower quarter, i.e. the lower index: the result
+// is the (distance, index)-lexicographic top-K, exactly what the single scan produces.
+template <int K>
+__global__ __launch_bounds__(256) void knn_split_kernel(const float* __restrict__ xyz, int N, int* __restrict__ idx) {
+  constexpr int kSlices = 4, kChunk = 512;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[kSlices * kChunk * 16 + kKnnQueue * 256 * 8];   // 32 KB stages + 16 KB queues
+  const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float4* s_ref = reinterpret_cast<float4*>(smem) + wave * kChunk;
+  float2 (*s_q)[256] = reinterpret_cast<float2 (*)[256]>(smem + kSlices * kChunk * 16);
+  const int qi = blockIdx.x * 64 + lane;
+  const float* __restrict__ p = xyz + (size_t)b * N * 3;
+  const bool ok = qi < N;
+  const float qx = ok ? p[qi * 3 + 0] : 0.f, qy = ok ? p[qi * 3 + 1] : 0.f, qz = ok ? p[qi * 3 + 2] : 0.f;
+  float bd[K];
+  int bi[K];
+#pragma unroll
+  for (int j = 0; j < K; ++j) { bd[j] = INFINITY; bi[j] = 0; }
+  int qn = 0;
+  float thr = INFINITY;
+  auto flush = [&]() {
+#pragma unroll 1
+    for (int s = 0; s < kKnnQueue; ++s) {
+      if (!__any(s < qn)) break;
+      const float2 e = s_q[s][tid];
+      float d = s < qn ? e.x : INFINITY;
+      int id = __float_as_int(e.y);
+#pragma unroll
+      for (int t = 0; t < K; ++t) {
+        const bool lt = d < bd[t];
+        const float td = bd[t]; const int ti = bi[t];
+        bd[t] = lt ? d : td;  bi[t] = lt ? id : ti;
+        d = lt ? td : d;      id = lt ? ti : id;
+      }
+    }
+    qn = 0;
+    thr = bd[K - 1];
+  };
+  const int len = (N + kSlices - 1) / kSlices, r_begin = wave * len, r_end = min(N, r_begin + len);
+  for (int r0 = r_begin; r0 < r_end; r0 += kChunk) {
+    const int cnt = min(kChunk, r_end - r0);
+    __builtin_amdgcn_wave_barrier();                       // this wave's stage is its own: LDS ops of a wave execute in order
+    for (int j = lane; j < cnt; j += 64) s_ref[j] = make_float4(p[(r0 + j) * 3], p[(r0 + j) * 3 + 1], p[(r0 + j) * 3 + 2], 0.f);
+    __builtin_amdgcn_wave_barrier();
+    for (int j = 0; j < cnt; ++j) {
+      const float4 r = s_ref[j];
+      const float d = metric_sqdist<0>(r.x - qx, r.y - qy, r.z - qz);
+      if (d < thr) {
+        s_q[qn][tid] = make_float2(d, __int_as_float(r0 + j));
+        ++qn;
+      }
+      if (__any(qn == kKnnQueue)) flush();
+    }
+  }
+  flush();
+  __syncthreads();                                         // every wave is done with its stage and queue: the lists take their place
+  float2 (*L)[K][64] = reinterpret_cast<float2 (*)[K][64]>(smem);   // [slice][rank][query], 4 x K x 64 x 8 B <= 48 KB for K <= 24
+  static_assert(kSlices * K * 64 * 8 <= (int)sizeof(smem), "the partial lists must fit the stage + queue area");
+#pragma unroll
+  for (int j = 0; j < K; ++j) L[wave][j][lane] = make_float2(bd[j], __int_as_float(bi[j]));
+  __syncthreads();
+  if (wave == 0 && ok) {
+    float cd[kSlices];
+    int ci[kSlices], h[kSlices];
+#pragma unroll
+    for (int s = 0; s < kSlices; ++s) { const float2 e = L[s][0][lane]; cd[s] = e.x; ci[s] = __float_as_int(e.y); h[s] = 0; }
+#pragma unroll 1
+    for (int j = 0; j < K; ++j) {
+      int best = 0;
+      float d = cd[0];
+      int id = ci[0];
+#pragma unroll
+      for (int s = 1; s < kSlices; ++s) {                  // strict <: on equal distances the lower quarter (lower index) stays
+        const bool lt = cd[s] < d;
+        d = lt ? cd[s] : d; id = lt ? ci[s] : id; best = lt ? s : best;
+      }
+      idx[((size_t)b * N + qi) * K + j] = id;
+      int hb = 0;
+#pragma unroll
+      for (int s = 0; s < kSlices; ++s) { h[s] += (s == best); hb = (s == best) ? h[s] : hb; }
+      const float2 e = (hb < K) ? L[best][hb][lane] : make_float2(INFINITY, 0.f);
+#pragma unroll
+      for (int s = 0; s < kSlices; ++s) { cd[s] = (s == best) ? e.x : cd[s]; ci[s] = (s == best) ? __float_as_int(e.y) : ci[s]; }
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // conv1 on the 6-channel edge feature (neighbour xyz, centre xyz) + folded BN + ReLU.  K = 6 is too thin for MFMA.
 // One thread per (point, neighbour, 4 output channels).  out[(b*N+n)*k + j][64]
@@ -262,7 +352,10 @@ extern "C" int houv_knn(const float* xyz, int B, int N, int k, int32_t* idx, voi
   }
   dim3 grid((N + 255) / 256, B);
   hipStream_t s = (hipStream_t)stream;
-  if (k == 20) knn_kernel<20><<<grid, 256, 0, s>>>(xyz, N, idx);
+  const bool split = N >= 512 && g_debug.knn_split.load() != 0;   // four waves per 64 queries, a quarter of the references each
+  if (k == 20 && split) knn_split_kernel<20><<<dim3((N + 63) / 64, B), 256, 0, s>>>(xyz, N, idx);
+  else if (k == 16 && split) knn_split_kernel<16><<<dim3((N + 63) / 64, B), 256, 0, s>>>(xyz, N, idx);
+  else if (k == 20) knn_kernel<20><<<grid, 256, 0, s>>>(xyz, N, idx);
   else if (k == 16) knn_kernel<16><<<grid, 256, 0, s>>>(xyz, N, idx);
   else if (k == 8) knn_kernel<8><<<grid, 256, 0, s>>>(xyz, N, idx);
   else if (k == 3) knn_kernel<3><<<grid, 256, 0, s>>>(xyz, N, idx);

@@ -36,6 +36,7 @@ inline bool check_launch(const char* what) {
 //   "chamfer_q"       queries per lane cap of the filtered Chamfer kernel (8)
 //   "gemm_4w" / "gemm_guarded"   houv_gemm_f32: 4-wave workgroups / always the guarded tile fetch
 //   "gemm_split"      houv_gemm_f32: 0 fp32-input MFMA, 6 / 3 = bf16 part products per fp32 product (gemm.hip, gemm_split_kernel)
+//   "knn_split"       houv_knn: 1 references split over the four waves of a workgroup (same lists), 0 the single-scan kernel
 //   "attn_split"      houv_attention_f32: 1 bf16 matrix pipe with three-part splits (full tiles), 0 fp32-input MFMA kernel
 struct DebugKnobs {
   std::atomic<int> pred_mode{0};
@@ -48,6 +49,7 @@ struct DebugKnobs {
   std::atomic<int> chamfer_q{8};
   std::atomic<int> gemm_4w{0};
   std::atomic<int> gemm_guarded{0};
+  std::atomic<int> knn_split{1};         // houv_knn (N >= 512, k = 16 / 20): four waves per 64 queries, a quarter of the references each; 0: one wave per 64 queries
   std::atomic<int> attn_split{1};        // houv_attention_f32 on the bf16 matrix pipe (attention.hip, attention_split_kernel); 0: fp32-input MFMA
   std::atomic<int> gemm_split{6};        // houv_gemm_f32 on the bf16 matrix pipe: 6 / 3 part products per fp32 product (0: fp32-input MFMA)
 };

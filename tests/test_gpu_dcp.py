@@ -38,6 +38,36 @@ def test_knn_matches_reference_formula(dev, B, N, k):
     assert (d[..., 1:] >= d[..., :-1] - 1e-7).all()        # nearest first
 
 
+@pytest.mark.parametrize("B,N,k", [(3, 2048, 20), (2, 513, 20), (2, 2047, 16), (1, 4100, 20), (2, 512, 16)])
+def test_knn_with_split_references_gives_the_same_lists(dev, B, N, k):
+    """houv_knn's default for N >= 512 (four waves per 64 queries, a quarter of the references each, merged in LDS) against the
+    single-scan kernel: identical lists.  With exact duplicates of points (distance ties) the single scan's insertion bubble is not
+    stable -- a displaced entry leapfrogs its equals -- while the merge is (distance, index)-lexicographic: there the DISTANCES of the
+    two lists must agree entry by entry and the split kernel's order must be the lexicographic one."""
+    from houv_amd import _lib, ops
+    gen = torch.Generator().manual_seed(N * 3 + k)
+    x = torch.rand(B, N, 3, generator=gen)
+
+    def both(cloud):
+        try:
+            _lib.debug_set("knn_split", 0)
+            single = ops.knn(cloud.to(dev), k).cpu().long()
+        finally:
+            _lib.debug_set("knn_split", 1)
+        return single, ops.knn(cloud.to(dev), k).cpu().long()
+
+    single, split = both(x)
+    np.testing.assert_array_equal(split.numpy(), single.numpy())
+    x[:, N // 2:N // 2 + 40] = x[:, :40]                      # exact duplicates in another quarter of the cloud
+    single, split = both(x)
+    d = lambda idx: ((x.double().unsqueeze(2) - torch.gather(x.double().unsqueeze(1).expand(B, N, N, 3), 2,
+                                                              idx.unsqueeze(-1).expand(B, N, k, 3))) ** 2).sum(-1)
+    ds, dp = d(single), d(split)
+    np.testing.assert_array_equal(dp.numpy(), ds.numpy())      # same neighbours up to exactly tied ones
+    tied = dp[..., 1:] == dp[..., :-1]
+    assert bool(((dp[..., 1:] >= dp[..., :-1]).all())) and bool((split[..., 1:][tied] > split[..., :-1][tied]).all())
+
+
 @pytest.mark.parametrize("M,N,K,tb", [(128, 128, 64, True), (300, 70, 130, True), (1000, 512, 512, True),
                                      (257, 64, 64, True), (200, 128, 333, False), (64, 96, 48, False), (5, 3, 7, True)])
 def test_gemm_plain(dev, M, N, K, tb):
