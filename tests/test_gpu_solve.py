@@ -514,3 +514,25 @@ def test_pruned_search_soak_over_edge_and_random_sizes():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "soak_pruned.py")], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "64 cases, 0 mismatches" in r.stdout
+
+
+def test_calc_cd_f1_branch(dev):
+    """calc_cd / calc_cd_percent with calc_f1=True (model_utils_completion.py:69-100, fscore.py:3-16): the harmonic mean of the
+    fractions of squared NN distances below 1e-4, per pair; 0 when no point is that close."""
+    from houv_amd import model_utils_completion as muc
+    gen = torch.Generator().manual_seed(5)
+    a = torch.rand(3, 300, 3, generator=gen)
+    b = a + 0.004 * torch.randn(3, 300, 3, generator=gen)        # NN distances straddle the 1e-2 threshold on the distance
+    b[2] += 5.0                                                  # a pair with nothing close: F-score 0, not NaN
+    cd_p, cd_t, f1 = muc.calc_cd(a.to(dev), b.to(dev), calc_f1=True)
+    d = ((b.double().unsqueeze(2) - a.double().unsqueeze(1)) ** 2).sum(-1)     # [B, gt=b, out=a]: cd()(gt, output) = (b -> a, a -> b)
+    d1, d2 = d.min(2)[0], d.min(1)[0]
+    p1, p2 = (d1 < 1e-4).double().mean(1), (d2 < 1e-4).double().mean(1)
+    want = torch.where(p1 + p2 > 0, 2 * p1 * p2 / (p1 + p2).clamp_min(1e-300), torch.zeros_like(p1))
+    np.testing.assert_allclose(f1.cpu().numpy(), want.numpy(), atol=1e-6)
+    assert float(f1[2]) == 0.0 and 0.0 < float(f1[0]) < 1.0
+    np.testing.assert_allclose(cd_t.cpu().numpy(), (d1.mean(1) + d2.mean(1)).numpy(), rtol=1e-5)
+    pp, pt, pf = muc.calc_cd_percent(a.to(dev), b.to(dev), calc_f1=True, percent=0.5)
+    k1, k2 = d1.topk(150, dim=1, largest=False)[0], d2.topk(150, dim=1, largest=False)[0]
+    q1, q2 = (k1 < 1e-4).double().mean(1), (k2 < 1e-4).double().mean(1)
+    np.testing.assert_allclose(pf.cpu().numpy(), torch.where(q1 + q2 > 0, 2 * q1 * q2 / (q1 + q2).clamp_min(1e-300), torch.zeros_like(q1)).numpy(), atol=1e-6)
