@@ -88,57 +88,70 @@ def morton_sort(cloud):
 KD_RULE = "extent"           # split axis: "extent" = the longest one | "area" = the one whose halves have the smallest projected area
 
 
+def _split_segments(seg, cut, rule):
+    """One k-d split of every segment of ``seg`` [S, L, 3] at position ``cut``: each segment reordered (stably) along its split axis."""
+    S, L, _ = seg.shape
+    if rule == "area":
+        # the view terms search in the three axis-dropped projections: pick the split whose two halves have the smallest
+        # summed projected box areas (ties: the lowest axis) -- ~5 % fewer sub-tile visits than the longest-axis rule
+        best = out = None
+        for ax in range(3):
+            o = torch.argsort(seg[..., ax], dim=1, stable=True)
+            cand = torch.gather(seg, 1, o.unsqueeze(2).expand(-1, -1, 3))
+
+            def area(x):
+                e = x.max(dim=1)[0] - x.min(dim=1)[0]
+                return e[:, 0] * e[:, 1] + e[:, 1] * e[:, 2] + e[:, 0] * e[:, 2]
+            cost = area(cand[:, :cut]) + area(cand[:, cut:])
+            if best is None:
+                best, out = cost, cand
+            else:
+                take = cost < best
+                best = torch.where(take, cost, best)
+                out = torch.where(take.view(S, 1, 1), cand, out)
+        return out
+    ext = seg.max(dim=1)[0] - seg.min(dim=1)[0]                          # [S,3]
+    axis = ext.argmax(dim=1)                                             # first maximum wins ties: deterministic
+    key = torch.gather(seg, 2, axis.view(S, 1, 1).expand(-1, L, 1))[..., 0]
+    order = torch.argsort(key, dim=1, stable=True)
+    return torch.gather(seg, 1, order.unsqueeze(2).expand(-1, -1, 3))
+
+
 def kd_sort(cloud, leaf=32, rule=None):
     """Reorder every cloud [P,N,3] so that consecutive runs of ``leaf`` points -- the kernel's 32-point sub-tiles -- are the leaves
     of a balanced k-d tree: the point range is halved (at a multiple of ``leaf``) along its longest axis, recursively.  Leaves of a
     k-d tree have tighter boxes than runs of a Morton curve (whose 32-runs straddle the curve's jumps), so the pruned search visits
     fewer sub-tiles.  The order is CANONICAL: it starts from the lexicographic (x, y, z) order and only uses stable sorts, so it is
     a function of the point SET -- sorting a sorted cloud again (or any permutation of it) gives the same order, which is what
-    lets bench.py hand identical clouds to both searches."""
+    lets bench.py hand identical clouds to both searches.  The segments of one tree level that have the same length and cut are
+    split in ONE batched call (all of them when N is leaf times a power of two: 6 calls instead of 63 at 2048 points)."""
     P, N, _ = cloud.shape
+    rule = rule or KD_RULE
     for ax in (2, 1, 0):                                    # lexicographic by (x, y, z): canonical starting order
         order = torch.argsort(cloud[..., ax], dim=1, stable=True)
         cloud = torch.gather(cloud, 1, order.unsqueeze(2).expand(-1, -1, 3))
     segs = [(0, N)]
     while True:
-        nxt, split = [], False
+        nxt, groups = [], {}
         for (a, b) in segs:
             tiles = -(-(b - a) // leaf)
             if tiles <= 1:
                 nxt.append((a, b))
                 continue
-            split = True
-            seg = cloud[:, a:b]
             mid = a + (tiles - tiles // 2) * leaf                                # left half gets the extra tile; a multiple of leaf
-            if (rule or KD_RULE) == "area":
-                # the view terms search in the three axis-dropped projections: pick the split whose two halves have the smallest
-                # summed projected box areas (ties: the lowest axis) -- ~5 % fewer sub-tile visits than the longest-axis rule
-                best = None
-                for ax in range(3):
-                    o = torch.argsort(seg[..., ax], dim=1, stable=True)
-                    cand = torch.gather(seg, 1, o.unsqueeze(2).expand(-1, -1, 3))
-
-                    def area(x):
-                        e = x.max(dim=1)[0] - x.min(dim=1)[0]
-                        return e[:, 0] * e[:, 1] + e[:, 1] * e[:, 2] + e[:, 0] * e[:, 2]
-                    cost = area(cand[:, :mid - a]) + area(cand[:, mid - a:])
-                    if best is None:
-                        best, out = cost, cand
-                    else:
-                        take = cost < best
-                        best = torch.where(take, cost, best)
-                        out = torch.where(take.view(P, 1, 1), cand, out)
-                cloud[:, a:b] = out
-            else:
-                ext = seg.max(dim=1)[0] - seg.min(dim=1)[0]                      # [P,3]
-                axis = ext.argmax(dim=1)                                         # first maximum wins ties: deterministic
-                key = torch.gather(seg, 2, axis.view(P, 1, 1).expand(-1, b - a, 1))[..., 0]
-                order = torch.argsort(key, dim=1, stable=True)
-                cloud[:, a:b] = torch.gather(seg, 1, order.unsqueeze(2).expand(-1, -1, 3))
+            groups.setdefault((b - a, mid - a), []).append(a)
             nxt += [(a, mid), (mid, b)]
-        segs = nxt
-        if not split:
+        if not groups:
             break
+        for (length, cut), starts in groups.items():
+            if len(starts) == 1:
+                a = starts[0]
+                cloud[:, a:a + length] = _split_segments(cloud[:, a:a + length], cut, rule)
+            else:                                                                # same shape: one batched split
+                idx = (torch.tensor(starts, device=cloud.device).view(-1, 1) + torch.arange(length, device=cloud.device).view(1, -1)).reshape(-1)
+                seg = cloud[:, idx].reshape(P * len(starts), length, 3)
+                cloud[:, idx] = _split_segments(seg, cut, rule).reshape(P, len(starts) * length, 3)
+        segs = nxt
     return cloud.contiguous()
 
 

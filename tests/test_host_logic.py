@@ -207,3 +207,31 @@ def test_kd_sort_is_canonical_and_compact():
     d1 = solver.kd_sort(dup.clone())
     assert torch.equal(solver.kd_sort(dup[:, torch.randperm(64, generator=torch.Generator().manual_seed(4))].clone()), d1)
     assert solver.SPATIAL_SORT == "kd" and torch.equal(solver.spatial_sort(src.clone()), a)
+
+
+def test_kd_sort_batched_levels_equal_the_per_segment_recursion():
+    """solver.kd_sort splits all same-shaped segments of a tree level in one batched call; the result must be the permutation the
+    plain per-segment recursion gives (restated here), for both split rules, power-of-two and ragged sizes, leaf 32 and 64."""
+    import torch
+    from houv_amd import solver, synthetic
+
+    def plain(cloud, leaf, rule):
+        for ax in (2, 1, 0):
+            cloud = torch.gather(cloud, 1, torch.argsort(cloud[..., ax], dim=1, stable=True).unsqueeze(2).expand(-1, -1, 3))
+
+        def rec(a, b):
+            tiles = -(-(b - a) // leaf)
+            if tiles <= 1:
+                return
+            mid = a + (tiles - tiles // 2) * leaf
+            cloud[:, a:b] = solver._split_segments(cloud[:, a:b].clone(), mid - a, rule)
+            rec(a, mid)
+            rec(mid, b)
+        rec(0, cloud.shape[1])
+        return cloud
+
+    src, _, _ = synthetic.make_pairs(2, 4096, seed=11)
+    for n, leaf in ((2048, 32), (1800, 32), (640, 32), (4096, 64), (3000, 64), (33, 32)):
+        for rule in ("extent", "area"):
+            x = src[:, :n].clone()
+            assert torch.equal(solver.kd_sort(x.clone(), leaf, rule), plain(x.clone(), leaf, rule)), (n, leaf, rule)
