@@ -85,7 +85,8 @@ def morton_sort(cloud):
     return torch.gather(cloud, 1, order.unsqueeze(2).expand(-1, -1, 3)).contiguous()
 
 
-KD_RULE = "extent"           # split axis: "extent" = the longest one | "area" = the one whose halves have the smallest projected area
+KD_RULE = "area"             # split axis: "area" = the one whose halves have the smallest projected box areas (default: -3 % kernel
+                             # time, the view metrics search in projections) | "extent" = the longest one
 
 
 def _split_segments(seg, cut, rule):
@@ -119,7 +120,7 @@ def _split_segments(seg, cut, rule):
 
 def kd_sort(cloud, leaf=32, rule=None):
     """Reorder every cloud [P,N,3] so that consecutive runs of ``leaf`` points -- the kernel's 32-point sub-tiles -- are the leaves
-    of a balanced k-d tree: the point range is halved (at a multiple of ``leaf``) along its longest axis, recursively.  Leaves of a
+    of a balanced k-d tree: the point range is halved (at a multiple of ``leaf``) along the axis ``KD_RULE`` picks, recursively.  Leaves of a
     k-d tree have tighter boxes than runs of a Morton curve (whose 32-runs straddle the curve's jumps), so the pruned search visits
     fewer sub-tiles.  The order is CANONICAL: it starts from the lexicographic (x, y, z) order and only uses stable sorts, so it is
     a function of the point SET -- sorting a sorted cloud again (or any permutation of it) gives the same order, which is what
