@@ -308,7 +308,7 @@ def bench_dcp(args, dev, world, rank):
     from houv_amd.models.houv import Predict_loss
     P = args.pairs
     torch.manual_seed(2021)
-    net = Model(None, pairs_per_chunk=int(os.environ.get("HOUV_DCP_CHUNK", 16))).to(dev)
+    net = Model(None, pairs_per_chunk=int(os.environ.get("HOUV_DCP_CHUNK", 32))).to(dev)
     batches = []
     for b in range(args.steps + args.warmup):
         s, t, _ = synthetic.make_pairs(P, args.points, seed=2021, first_id=(b * world + rank) * P)
