@@ -11,7 +11,8 @@
 namespace houv {
 
 constexpr int kWave = 64;     // CDNA wavefront
-constexpr int kSub = 32;      // reference points per arg-min tracking sub-tile (see DESIGN.md "deferred index")
+constexpr int kSub = 32;      // reference points per sub-tile: padding unit, bounding boxes and visit masks of the pruned search
+constexpr int kTrk = 16;      // reference points per arg-min TRACKING unit (half a sub-tile): what `btile` counts and a rescan re-reads
 
 // ---- host side ---------------------------------------------------------------------------------
 void set_error(const char* fmt, ...);

@@ -12,7 +12,7 @@ typedef const houv_f4v __attribute__((address_space(3))) * lds_f4;   // LDS poin
 
 // ------------------------------------------------------------------------------------------------
 // The brute-force sweep: for each of this lane's Q queries, min over all references of the NMET
-// squared distances, plus the id of the 32-reference sub-tile that produced each minimum.
+// squared distances, plus the id of the 16-reference tracking unit (kTrk) that produced each minimum.
 // ------------------------------------------------------------------------------------------------
 // One sub-tile of the sweep: out = min(in, the sub-tile's distances), per query and metric.  `in` and `out` are DIFFERENT
 // register sets (the first v_min3 of a chain is three-address: out = min3(in, a, c)), so the caller can compare out against in
@@ -21,7 +21,7 @@ template <int Q, int NMET>
 __device__ __forceinline__ void sweep_tile(const float4* __restrict__ rp, const float (&qx)[Q], const float (&qy)[Q],
                                            const float (&qz)[Q], const float (&in)[Q][NMET], float (&out)[Q][NMET]) {
 #pragma unroll
-  for (int j = 0; j < kSub; j += 2) {
+  for (int j = 0; j < kTrk; j += 2) {
     const float4 a = rp[j], c = rp[j + 1];
     // keep .w "used" so the loads stay ds_read_b128 (4 LDS cycles) instead of ds_read_b96 (8)
     asm volatile("" ::"v"(a.w), "v"(c.w));
@@ -63,19 +63,19 @@ __device__ __forceinline__ void sweep(const float4* __restrict__ refs, int ntile
     }
   int t = 0;
   for (; t + 1 < ntile; t += 2) {
-    sweep_tile<Q, NMET>(refs + t * kSub, qx, qy, qz, best, other);
+    sweep_tile<Q, NMET>(refs + t * kTrk, qx, qy, qz, best, other);
 #pragma unroll
     for (int k = 0; k < Q; ++k)
 #pragma unroll
       for (int m = 0; m < NMET; ++m) btile[k][m] = (other[k][m] < best[k][m]) ? t : btile[k][m];
-    sweep_tile<Q, NMET>(refs + (t + 1) * kSub, qx, qy, qz, other, best);
+    sweep_tile<Q, NMET>(refs + (t + 1) * kTrk, qx, qy, qz, other, best);
 #pragma unroll
     for (int k = 0; k < Q; ++k)
 #pragma unroll
       for (int m = 0; m < NMET; ++m) btile[k][m] = (best[k][m] < other[k][m]) ? t + 1 : btile[k][m];
   }
   if (t < ntile) {   // odd number of sub-tiles
-    sweep_tile<Q, NMET>(refs + t * kSub, qx, qy, qz, best, other);
+    sweep_tile<Q, NMET>(refs + t * kTrk, qx, qy, qz, best, other);
 #pragma unroll
     for (int k = 0; k < Q; ++k)
 #pragma unroll
@@ -101,9 +101,9 @@ __device__ __forceinline__ void sweep_one(const float4* __restrict__ refs, int n
     float tm[Q];
 #pragma unroll
     for (int k = 0; k < Q; ++k) tm[k] = INFINITY;
-    const float4* rp = refs + t * kSub;
+    const float4* rp = refs + t * kTrk;
 #pragma unroll 4
-    for (int j = 0; j < kSub; j += 2) {
+    for (int j = 0; j < kTrk; j += 2) {
       const float4 a = rp[j], c = rp[j + 1];
       asm volatile("" ::"v"(a.w), "v"(c.w));
 #pragma unroll
@@ -151,31 +151,29 @@ __device__ __forceinline__ unsigned shift_in_mask(unsigned acc, unsigned long lo
 }
 __device__ __forceinline__ unsigned shift_in(unsigned acc, bool bit) { return shift_in_mask(acc, __builtin_amdgcn_ballot_w64(bit)); }
 
-// Exact NN recovery for one query: re-evaluate the winning 32-reference sub-tile with the bit-identical expression
-// and return the lowest matching reference.  The scan order is rotated per lane: sub-tile bases are 512 B apart, so an
+// Exact NN recovery for one query: re-evaluate the winning 16-reference tracking unit (kTrk; half a sub-tile -- the sweeps and the
+// pruned walks track the arg-min at this granularity since the end of round 3: half the re-evaluations) with the bit-identical
+// expression and return the lowest matching reference.  The scan order is rotated per lane: units are 256 B apart, so an
 // un-rotated scan puts all lanes of a ds_read_b128 group on the same LDS bank quad.
-// XOR512 (the cloud is 512-B aligned in LDS): lane l reads slot (i ^ (l & 15)) of BOTH 256-B halves of the sub-tile -- 16
-// distinct slots in each of the instruction's 16-lane groups, one v_xor per TWO reads (the second is an immediate offset) --
-// and collects the matches as one bit per read (shift_in); the lowest matching index is decoded after the scan (one
-// match unless two references tie exactly).  Otherwise: (j + rot) mod 32 with rot = lane & 31, min-tracked.
-template <int MET, int BATCH, bool XOR512 = false>
+// XOR256 (the cloud is 256-B aligned in LDS): lane l reads slot (i ^ (l & 15)) -- 16 distinct slots in each of the instruction's
+// 16-lane groups -- and collects the matches as one bit per read (shift_in); the lowest matching index is decoded after the scan
+// (one match unless two references tie exactly).  Otherwise: (j + rot) mod 16, min-tracked.
+template <int MET, int BATCH, bool XOR256 = false>
 __device__ __forceinline__ float4 recover_nn(const float4* __restrict__ rp, float qx, float qy, float qz, float bd, int rot,
                                              int& j_out) {
-  int jb = kSub;
-  if constexpr (XOR512) {
-    static_assert(BATCH % 2 == 0 && (kSub / 2) % (BATCH / 2) == 0 && kSub == 32, "reads come in pairs 256 B apart");
+  int jb = kTrk;
+  static_assert(kTrk == 16 && kTrk % BATCH == 0, "one 256-B unit of 16 slots");
+  if constexpr (XOR256) {
     const unsigned r16 = (unsigned)rot & 15u;
     const unsigned xa = (unsigned)(size_t)(lds_f4)rp + (r16 << 4);
-    unsigned match = 0u;                          // bit (31 - e) = read e matched; e = 2 * i + half
+    unsigned match = 0u;                          // bit (31 - e) = read e matched
 #pragma unroll 1
-    for (int c = 0; c < kSub / 2; c += BATCH / 2) {
+    for (int c = 0; c < kTrk; c += BATCH) {
       float4 r[BATCH];
 #pragma unroll
-      for (int u = 0; u < BATCH; u += 2) {
-        lds_f4 p = (lds_f4)(size_t)(xa ^ ((unsigned)(c + u / 2) << 4));
-        const houv_f4v v0 = p[0], v1 = p[kSub / 2];
-        r[u] = make_float4(v0.x, v0.y, v0.z, v0.w);
-        r[u + 1] = make_float4(v1.x, v1.y, v1.z, v1.w);
+      for (int u = 0; u < BATCH; ++u) {
+        const houv_f4v v = *(lds_f4)(size_t)(xa ^ ((unsigned)(c + u) << 4));
+        r[u] = make_float4(v.x, v.y, v.z, v.w);
       }
 #pragma unroll
       for (int u = 0; u < BATCH; ++u) asm volatile("" ::"v"(r[u].x), "v"(r[u].y), "v"(r[u].z), "v"(r[u].w));   // keep b128
@@ -183,27 +181,28 @@ __device__ __forceinline__ float4 recover_nn(const float4* __restrict__ rp, floa
       for (int u = 0; u < BATCH; ++u)
         match = shift_in(match, metric_sqdist<MET>(r[u].x - qx, r[u].y - qy, r[u].z - qz) == bd);
     }
+    match <<= 32 - kTrk;                          // read e at bit 31 - e
     while (match != 0u) {                         // one round unless references tie (or none: not a point)
       const int e = __clz((int)match);
       match &= ~(0x80000000u >> e);
-      jb = min(jb, (int)(((unsigned)(e >> 1) ^ r16) + (unsigned)(e & 1) * (kSub / 2)));
+      jb = min(jb, (int)((unsigned)e ^ r16));
     }
   } else {
 #pragma unroll 1
-    for (int c = 0; c < kSub; c += BATCH) {
+    for (int c = 0; c < kTrk; c += BATCH) {
       float4 r[BATCH];
 #pragma unroll
-      for (int u = 0; u < BATCH; ++u) r[u] = rp[(c + u + rot) & (kSub - 1)];
+      for (int u = 0; u < BATCH; ++u) r[u] = rp[(c + u + rot) & (kTrk - 1)];
 #pragma unroll
       for (int u = 0; u < BATCH; ++u) asm volatile("" ::"v"(r[u].x), "v"(r[u].y), "v"(r[u].z), "v"(r[u].w));   // keep b128
 #pragma unroll
       for (int u = 0; u < BATCH; ++u) {
         const float d = metric_sqdist<MET>(r[u].x - qx, r[u].y - qy, r[u].z - qz);
-        jb = min(jb, (d == bd) ? ((c + u + rot) & (kSub - 1)) : kSub);   // lowest matching index, whatever the order
+        jb = min(jb, (d == bd) ? ((c + u + rot) & (kTrk - 1)) : kTrk);   // lowest matching index, whatever the order
       }
     }
   }
-  j_out = jb & (kSub - 1);
+  j_out = jb & (kTrk - 1);
   return rp[j_out];
 }
 
@@ -250,59 +249,60 @@ __device__ __forceinline__ int pt_index(int k) {
 #define HOUV_PRUNE_GROUP 1
 #endif
 
-// Minimum of the NMET squared distances between G queries and the 32 references of ONE sub-tile, gathered per lane: the lane's
-// sub-tile starts at LDS byte address (xa & ~511); the scan order is rotated per lane by XOR over the 16 slots of a 256-B half --
-// xa carries (lane & 15) << 4 in bits 4..7 -- and both halves are read through one address (the second read is an immediate
-// offset: one v_xor per TWO reads); needs the clouds 512-B aligned in LDS (solve.hip aligns the dynamic segment); conflict-free
-// as (lane ^ i) % 16 takes 16 distinct slots in every ds_read_b128 lane group.  The reads are software-pipelined: while a batch
-// of four references is being evaluated the next batch is in flight (ping-pong register sets; the trailing prefetch wraps
-// around and is dropped).  Same expression trees as sweep_tile(); the order inside a sub-tile does not matter to a minimum.
-// INIT = false: tm comes in holding the running minima (the caller compares against its copy afterwards).
-template <int G, int NMET, bool INIT = true>
+// Minima of the NMET squared distances between G queries and the 32 references of ONE sub-tile, gathered per lane, SEPARATELY for the
+// sub-tile's two tracking units (references 0..15 -> ta, 16..31 -> tb).  The lane's sub-tile starts at LDS byte address
+// (xa & ~511); the scan order is rotated per lane by XOR over the 16 slots of a 256-B half -- xa carries (lane & 15) << 4 in bits
+// 4..7 -- and both halves are read through one address (the second read is an immediate offset: one v_xor per TWO reads); needs the
+// clouds 512-B aligned in LDS (solve.hip aligns the dynamic segment); conflict-free as (lane ^ i) % 16 takes 16 distinct slots in
+// every ds_read_b128 lane group.  A min3 takes two references of the SAME half, so the two accumulators cost no instruction more
+// than one.  The reads are software-pipelined: while a batch of four references is being evaluated the next batch is in flight
+// (ping-pong register sets; the trailing prefetch wraps around and is dropped).  Same expression trees as sweep_tile(); the order
+// inside a tracking unit does not matter to a minimum.  ta comes in holding whatever the caller threads through the first unit
+// (its running minima, or +inf); tb is set here.
+template <int G, int NMET>
 __device__ __forceinline__ void gather_tile_min(unsigned xa, const float (&cx)[G], const float (&cy)[G], const float (&cz)[G],
-                                                float (&tm)[G][NMET]) {
-  if constexpr (INIT) {
+                                                float (&ta)[G][NMET], float (&tb)[G][NMET]) {
 #pragma unroll
-    for (int k = 0; k < G; ++k)
+  for (int k = 0; k < G; ++k)
 #pragma unroll
-      for (int m = 0; m < NMET; ++m) tm[k][m] = INFINITY;
-  }
+    for (int m = 0; m < NMET; ++m) tb[k][m] = INFINITY;
   constexpr int kBatch = 4, kHalf = kSub / 2;
-  static_assert(kSub == 32, "two 256-B halves of 16 slots");
+  static_assert(kSub == 32 && kHalf == kTrk, "two 256-B tracking units of 16 slots");
   auto fetch = [&](float4 (&r)[kBatch], int i0) {
 #pragma unroll
     for (int u = 0; u < kBatch; u += 2) {
       lds_f4 p = (lds_f4)(size_t)(xa ^ ((unsigned)((i0 + u / 2) & (kHalf - 1)) << 4));
       const houv_f4v v0 = p[0], v1 = p[kHalf];
-      r[u] = make_float4(v0.x, v0.y, v0.z, v0.w);
-      r[u + 1] = make_float4(v1.x, v1.y, v1.z, v1.w);
+      r[u] = make_float4(v0.x, v0.y, v0.z, v0.w);           // first unit
+      r[u + 1] = make_float4(v1.x, v1.y, v1.z, v1.w);       // second unit
+    }
+  };
+  auto eval2 = [&](const float4 a, const float4 c, float (&t)[G][NMET]) {   // two references of one unit
+#pragma unroll
+    for (int k = 0; k < G; ++k) {
+      const float ax = a.x - cx[k], ay = a.y - cy[k], az = a.z - cz[k];
+      const float bx = c.x - cx[k], by = c.y - cy[k], bz = c.z - cz[k];
+      if constexpr (NMET == 4) {
+        const float axx = ax * ax, ayy = ay * ay, bxx = bx * bx, byy = by * by;
+        const float a3 = __builtin_fmaf(ay, ay, axx), b3 = __builtin_fmaf(by, by, bxx);
+        const float a1 = __builtin_fmaf(az, az, ayy), b1 = __builtin_fmaf(bz, bz, byy);
+        const float a2 = __builtin_fmaf(az, az, axx), b2 = __builtin_fmaf(bz, bz, bxx);
+        const float a0 = __builtin_fmaf(az, az, a3), b0 = __builtin_fmaf(bz, bz, b3);
+        t[k][0] = min3f(t[k][0], a0, b0);
+        t[k][1] = min3f(t[k][1], a1, b1);
+        t[k][2] = min3f(t[k][2], a2, b2);
+        t[k][3] = min3f(t[k][3], a3, b3);
+      } else {
+        t[k][0] = min3f(t[k][0], metric_sqdist<0>(ax, ay, az), metric_sqdist<0>(bx, by, bz));
+      }
     }
   };
   auto eval = [&](float4 (&r)[kBatch]) {
 #pragma unroll
     for (int u = 0; u < kBatch; ++u) asm volatile("" ::"v"(r[u].x), "v"(r[u].y), "v"(r[u].z), "v"(r[u].w));   // keep b128
-#pragma unroll
-    for (int u = 0; u < kBatch; u += 2) {
-      const float4 a = r[u], c = r[u + 1];
-#pragma unroll
-      for (int k = 0; k < G; ++k) {
-        const float ax = a.x - cx[k], ay = a.y - cy[k], az = a.z - cz[k];
-        const float bx = c.x - cx[k], by = c.y - cy[k], bz = c.z - cz[k];
-        if constexpr (NMET == 4) {
-          const float axx = ax * ax, ayy = ay * ay, bxx = bx * bx, byy = by * by;
-          const float a3 = __builtin_fmaf(ay, ay, axx), b3 = __builtin_fmaf(by, by, bxx);
-          const float a1 = __builtin_fmaf(az, az, ayy), b1 = __builtin_fmaf(bz, bz, byy);
-          const float a2 = __builtin_fmaf(az, az, axx), b2 = __builtin_fmaf(bz, bz, bxx);
-          const float a0 = __builtin_fmaf(az, az, a3), b0 = __builtin_fmaf(bz, bz, b3);
-          tm[k][0] = min3f(tm[k][0], a0, b0);
-          tm[k][1] = min3f(tm[k][1], a1, b1);
-          tm[k][2] = min3f(tm[k][2], a2, b2);
-          tm[k][3] = min3f(tm[k][3], a3, b3);
-        } else {
-          tm[k][0] = min3f(tm[k][0], metric_sqdist<0>(ax, ay, az), metric_sqdist<0>(bx, by, bz));
-        }
-      }
-    }
+    static_assert(kBatch == 4, "a batch = two slots x two units");
+    eval2(r[0], r[2], ta);
+    eval2(r[1], r[3], tb);
   };
   float4 ra[kBatch], rb[kBatch];
   fetch(ra, 0);
@@ -313,6 +313,14 @@ __device__ __forceinline__ void gather_tile_min(unsigned xa, const float (&cx)[G
     fetch(ra, i0 + kBatch);
     eval(rb);
   }
+}
+
+// (running minimum, tracking unit) of one query and metric after a sub-tile whose unit minima are ta -- threaded: already
+// min(running, first unit) -- and tb (second unit).  Units are taken in ascending order with strict <, as sweep() takes them.
+__device__ __forceinline__ void take_units(float ta, float tb, int unit0, float& cb, int& ct) {
+  const bool la = ta < cb, lb = tb < ta;
+  ct = lb ? unit0 + 1 : (la ? unit0 : ct);
+  cb = lb ? tb : ta;
 }
 
 // Which sub-tiles each of this lane's queries must visit: the bound per metric is the distance to the point that was the
@@ -471,16 +479,16 @@ __device__ __forceinline__ void pruned_sweep(const float4* __restrict__ refs, co
         t = (mm != 0ull) ? (__ffsll((long long)mm) - 1) : t;
         un[g] = mm & (mm - 1ull);                              // 0 stays 0
         const unsigned xa = (unsigned)(size_t)(lds_f4)refs + (unsigned)t * (kSub * 16u) + (((unsigned)rot & 15u) << 4);
-        float tm[G][NMET];
-        gather_tile_min<G, NMET>(xa, cx, cy, cz, tm);
+        float ta[G][NMET], tb[G][NMET];
 #pragma unroll
         for (int k = 0; k < G; ++k)
 #pragma unroll
-          for (int m = 0; m < NMET; ++m) {
-            const bool lt = tm[k][m] < best[g * G + k][m];
-            best[g * G + k][m] = lt ? tm[k][m] : best[g * G + k][m];
-            btile[g * G + k][m] = lt ? t : btile[g * G + k][m];
-          }
+          for (int m = 0; m < NMET; ++m) ta[k][m] = best[g * G + k][m];   // the running minima threaded through the first unit
+        gather_tile_min<G, NMET>(xa, cx, cy, cz, ta, tb);
+#pragma unroll
+        for (int k = 0; k < G; ++k)
+#pragma unroll
+          for (int m = 0; m < NMET; ++m) take_units(ta[k][m], tb[k][m], 2 * t, best[g * G + k][m], btile[g * G + k][m]);
       }
       nsteps += cap;
     }
@@ -520,17 +528,24 @@ __device__ __forceinline__ void pruned_sweep(const float4* __restrict__ refs, co
       }
     }
     const unsigned xa = (unsigned)(size_t)(lds_f4)refs + (unsigned)t * (kSub * 16u) + (((unsigned)rot & 15u) << 4);
-    float tm[G][NMET];
-    gather_tile_min<G, NMET>(xa, cx, cy, cz, tm);
+    float ta[G][NMET], tb[G][NMET];
+#pragma unroll
+    for (int k = 0; k < G; ++k)
+#pragma unroll
+      for (int m = 0; m < NMET; ++m) ta[k][m] = INFINITY;               // which list the lane is on is only known per lane: fresh minima
+    gather_tile_min<G, NMET>(xa, cx, cy, cz, ta, tb);
 #pragma unroll
     for (int g = 0; g < L; ++g)
 #pragma unroll
       for (int k = 0; k < G; ++k)
 #pragma unroll
         for (int m = 0; m < NMET; ++m) {
-          const bool lt = act && (cur == g) && (tm[k][m] < best[g * G + k][m]);
-          best[g * G + k][m] = lt ? tm[k][m] : best[g * G + k][m];
-          btile[g * G + k][m] = lt ? t : btile[g * G + k][m];
+          const bool on = act && (cur == g);
+          const bool lb = tb[k][m] < ta[k][m];                          // the second unit holds the sub-tile's minimum (strictly)
+          const float tmin = lb ? tb[k][m] : ta[k][m];
+          const bool lt = on && (tmin < best[g * G + k][m]);
+          best[g * G + k][m] = lt ? tmin : best[g * G + k][m];
+          btile[g * G + k][m] = lt ? 2 * t + (lb ? 1 : 0) : btile[g * G + k][m];
         }
   }
   if (stats && (threadIdx.x & 63) == 0) atomicAdd(&stats[1], (unsigned long long)nsteps);
@@ -565,9 +580,9 @@ struct SortedStage {
 __device__ __forceinline__ unsigned& w_slot(float4* cloud, int q) { return reinterpret_cast<unsigned*>(cloud + q)[3]; }
 
 // wlo / whi: the two LDS clouds (both hold >= count entries); .w of wlo[q] carries the low half of query q's mask and,
-// after the walk, the sub-tile ids of its minima; .w of whi[q] the high half.
+// after the walk, the tracking-unit ids (8 bits each: <= 256 units of 16 references) of its minima; .w of whi[q] the high half.
 // TS = 1 (clouds of 2049..4096 points): the masks are over 64 SUPER-tiles of two sub-tiles each (`boxes`, `ntile` count
-// super-tiles); a visit evaluates both sub-tiles in ascending order, the minima still carry SUB-tile ids (0..127) for the rescans.
+// super-tiles); a visit evaluates both sub-tiles in ascending order, the minima carry tracking-unit ids (0..255) for the rescans.
 template <int BLOCK, int Q, int NMET, int TS = 0>
 __device__ __forceinline__ void pruned_sweep_sorted(const float4* __restrict__ refs, const float4* __restrict__ boxes, int ntile,
                                                     const float4* __restrict__ qarr, float4* wlo, float4* whi,
@@ -643,15 +658,12 @@ __device__ __forceinline__ void pruned_sweep_sorted(const float4* __restrict__ r
       for (int h = 0; h < (1 << TS); ++h) {
         const int ts = (t << TS) | h;                                   // sub-tile
         const unsigned xa = (unsigned)(size_t)(lds_f4)refs + (unsigned)ts * (kSub * 16u) + (((unsigned)rot & 15u) << 4);
-        float tm[1][NMET];                                              // the running minima threaded through the sub-tile
+        float ta[1][NMET], tb[1][NMET];                                 // the running minima threaded through the first tracking unit
 #pragma unroll
-        for (int m = 0; m < NMET; ++m) tm[0][m] = cb[m];
-        gather_tile_min<1, NMET, false>(xa, cx, cy, cz, tm);
+        for (int m = 0; m < NMET; ++m) ta[0][m] = cb[m];
+        gather_tile_min<1, NMET>(xa, cx, cy, cz, ta, tb);
 #pragma unroll
-        for (int m = 0; m < NMET; ++m) {
-          ct[m] = (tm[0][m] < cb[m]) ? ts : ct[m];                      // strictly lower than before: this sub-tile holds it
-          cb[m] = tm[0][m];
-        }
+        for (int m = 0; m < NMET; ++m) take_units(ta[0][m], tb[0][m], 2 * ts, cb[m], ct[m]);
       }
     }
     if (valid) {

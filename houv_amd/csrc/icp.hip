@@ -95,7 +95,7 @@ __global__ __launch_bounds__(BLOCK) void icp_kernel(IcpArgs a) {
     }
     float best[Q][1];
     int btile[Q][1];
-    sweep<Q, 1>(s_tgt, mpad / kSub, px, py, pz, best, btile);
+    sweep<Q, 1>(s_tgt, mpad / kTrk, px, py, pz, best, btile);
     // correspondences: NN strictly inside the search radius
     float nx[Q], ny[Q], nz[Q];
     bool in[Q];
@@ -103,7 +103,7 @@ __global__ __launch_bounds__(BLOCK) void icp_kernel(IcpArgs a) {
 #pragma unroll
     for (int k = 0; k < Q; ++k) {
       int jn;
-      const float4 nn = recover_nn<0, 4>(s_tgt + btile[k][0] * kSub, px[k], py[k], pz[k], best[k][0], rot, jn);
+      const float4 nn = recover_nn<0, 4>(s_tgt + btile[k][0] * kTrk, px[k], py[k], pz[k], best[k][0], rot, jn);
       nx[k] = nn.x; ny[k] = nn.y; nz[k] = nn.z;
       in[k] = ((k * BLOCK + tid) < N) && (best[k][0] < a.max_dist2);
       if (in[k]) {

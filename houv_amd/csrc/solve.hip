@@ -317,8 +317,8 @@ __device__ __forceinline__ void lane_grad_sums(const Smem& sm, const float4* __r
 #pragma unroll
   for (int k = 0; k < Q; ++k) {
     int jn;
-    const float4 nn = recover_nn<MET, kRescanBatch, true>(refs + bt[k] * kSub, qx[k], qy[k], qz[k], bd[k], rot, jn);
-    if (ws && pt_index<BLOCK, Q, OWN>(k) < count) ws[pt_index<BLOCK, Q, OWN>(k)] = (short)(bt[k] * kSub + jn);
+    const float4 nn = recover_nn<MET, kRescanBatch, true>(refs + bt[k] * kTrk, qx[k], qy[k], qz[k], bd[k], rot, jn);
+    if (ws && pt_index<BLOCK, Q, OWN>(k) < count) ws[pt_index<BLOCK, Q, OWN>(k)] = (short)(bt[k] * kTrk + jn);
     if ((selbits >> k) & 1u) {
       const float s = (bd[k] < INFINITY) ? sqrtf(bd[k]) : NAN;
       const float inv = 1.0f / s;   // d == 0 -> inf, and 0*inf = NaN below, as torch's sqrt backward gives
@@ -441,7 +441,7 @@ __device__ __forceinline__ void repair_direction_a(const Smem& sm, const float* 
   }
   float bd[Q];
   int bt[Q];
-  sweep_one<Q, MET>(sm.tgt, mpad / kSub, mx, my, mz, bd, bt);
+  sweep_one<Q, MET>(sm.tgt, mpad / kTrk, mx, my, mz, bd, bt);
   bool sel[Q];
   unsigned key[Q], bits = 0u;
 #pragma unroll
@@ -591,7 +591,7 @@ __global__ __launch_bounds__(BLOCK, (Q == 1 ? 8 : 4)) void solve_kernel(SolveArg
           pruned_sweep<BLOCK, Q, NMET, OWN>(sm.tgt, sm.tbox, mpad / kSub, mx, my, mz, ws_a, a.ws_stride, N, rot, best, btile, a.stats, a.cap_slack);
         }
       } else {
-        sweep<Q, NMET>(sm.tgt, mpad / kSub, mx, my, mz, best, btile);
+        sweep<Q, NMET>(sm.tgt, mpad / kTrk, mx, my, mz, best, btile);
         if (a.stats && (tid & 63) == 0) atomicAdd(&a.stats[3], 1ull);
       }
       HOUV_STAMP(1);
@@ -626,7 +626,7 @@ __global__ __launch_bounds__(BLOCK, (Q == 1 ? 8 : 4)) void solve_kernel(SolveArg
           pruned_sweep<BLOCK, Q, NMET, OWN>(sm.mov, sm.mbox, npad / kSub, tx, ty, tz, ws_b, a.ws_stride, M, rot, best, btile, a.stats, a.cap_slack);
         }
       } else {
-        sweep<Q, NMET>(sm.mov, npad / kSub, tx, ty, tz, best, btile);
+        sweep<Q, NMET>(sm.mov, npad / kTrk, tx, ty, tz, best, btile);
         if (a.stats && (tid & 63) == 0) atomicAdd(&a.stats[3], 1ull);
       }
       HOUV_STAMP(3);

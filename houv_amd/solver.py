@@ -4,6 +4,8 @@ it), chunked launches of houv_solve_iterate, and the best-of-K + angle-window re
 import os
 
 import numpy as np
+import weakref
+
 import torch
 
 from . import ops
@@ -159,22 +161,18 @@ def kd_sort(cloud, leaf=32, rule=None):
 SPATIAL_SORT = "kd"          # "kd" (balanced k-d leaves, round 3) | "morton" (rounds 1-2)
 
 
-_SORTED = {}                 # data_ptr -> (version, shape, device, order) of tensors spatial_sort itself produced
+_SORTED = {}                 # data_ptr -> (version, shape, device, order, leaf, weakref) of tensors spatial_sort itself produced
 
 
 def spatial_sort(cloud, leaf=32):
     """The point order the pruned search wants (spatially compact 32-point sub-tiles; ``leaf`` = 64 for clouds of more than 2048
     points, whose visit masks are over 64-point super-tiles).  A tensor this function returned is
-    recognised (address, version counter, shape) and handed back as it is: callers that keep their clouds sorted (bench.py,
-    the drivers' batches) do not pay for the sort again in every stage.  A stale match (the address re-used by another tensor
-    of the same shape) is harmless: the pruned search is exact for ANY point order, an unsorted cloud only makes it slower."""
-    mark = (cloud._version, tuple(cloud.shape), cloud.device, SPATIAL_SORT, leaf)
-    if cloud.is_contiguous() and _SORTED.get(cloud.data_ptr()) == mark:
+    recognised (the same tensor object: address, version counter, shape, weak reference) and handed back as it is: callers that keep their clouds sorted (bench.py,
+    the drivers' batches) do not pay for the sort again in every stage."""
+    if _sorted_leaf(cloud) == leaf:
         return cloud
     out = kd_sort(cloud, leaf) if SPATIAL_SORT == "kd" else morton_sort(cloud)
-    if len(_SORTED) > 512:
-        _SORTED.clear()
-    _SORTED[out.data_ptr()] = (out._version, tuple(out.shape), out.device, SPATIAL_SORT, leaf)
+    _mark_sorted(out, leaf)
     return out
 
 
@@ -186,12 +184,20 @@ def sort_leaf(N, M):
 def _sorted_leaf(cloud):
     """Leaf size a (contiguous) tensor was spatially sorted with, or None when it is not known to be sorted."""
     m = _SORTED.get(cloud.data_ptr()) if cloud.is_contiguous() else None
-    return m[4] if m is not None and m[:4] == (cloud._version, tuple(cloud.shape), cloud.device, SPATIAL_SORT) else None
+    # the entry must be about THIS tensor object: a freed tensor's address is soon re-used by another of the same shape, and an
+    # unsorted cloud taken for a sorted one is still solved exactly but in another summation order (and slower)
+    ok = m is not None and m[5]() is cloud and m[:4] == (cloud._version, tuple(cloud.shape), cloud.device, SPATIAL_SORT + KD_RULE)
+    return m[4] if ok else None
 
 
 def _mark_sorted(cloud, leaf):
     """Record that every cloud of this (contiguous) tensor is in spatial_sort order -- e.g. a row subset of a sorted batch."""
-    _SORTED[cloud.data_ptr()] = (cloud._version, tuple(cloud.shape), cloud.device, SPATIAL_SORT, leaf)
+    if len(_SORTED) > 512:
+        for key in [k for k, v in _SORTED.items() if v[5]() is None]:
+            del _SORTED[key]
+        if len(_SORTED) > 512:
+            _SORTED.clear()
+    _SORTED[cloud.data_ptr()] = (cloud._version, tuple(cloud.shape), cloud.device, SPATIAL_SORT + KD_RULE, leaf, weakref.ref(cloud))
 
 
 FUSED_MAX_POINTS = 4096     # both clouds of a hypothesis live in LDS inside the fused kernel (houv_solve_iterate)
